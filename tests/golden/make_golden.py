@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE UNMODIFIED REFERENCE.
+
+    make -C oracle ref            # builds oracle/_ref/ecloop_* from /root/reference (sources stay there)
+    python tests/golden/make_golden.py
+
+Only inputs and outputs are stored (no reference text).  Needs /root/reference/data for the two
+reference-owned input lists; everything else is synthesised here.  Output: tests/golden/golden.json
+(+ .npz files for the per-key dumps).  The all-ones-.blf trick turns the reference into a
+per-key hash160 dump: a bloom filter whose every bit is set reports every hashed key as "found".
+"""
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from synth import synth_bloom_words, write_blf  # noqa: E402  (shared with the tests: same inputs)
+
+REF_DATA = "/root/reference/data"
+
+
+def ref_bin():
+    for name in ("ecloop_sane", "ecloop_avx2", "ecloop_native"):
+        p = os.path.join(ROOT, "oracle", "_ref", name)
+        if os.path.exists(p):
+            return p
+    raise SystemExit("build the reference first: make -C oracle ref")
+
+
+def run_ref(args, stdin=None):
+    """Run the reference with -t 1 -q -o <tmp>; return (sorted found lines, final status line)."""
+    with tempfile.NamedTemporaryFile("r", suffix=".txt", delete=False) as out:
+        path = out.name
+    try:
+        cmd = [ref_bin()] + args + ["-q", "-o", path]
+        pr = subprocess.run(cmd, stdin=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        with open(path) as f:
+            lines = [l.rstrip("\n") for l in f if l.strip()]
+        status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
+        return sorted(lines), status
+    finally:
+        os.unlink(path)
+
+
+def digest(lines):
+    return hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest()
+
+
+def parse(lines):
+    """found lines -> (compressed u8[N], h160 u32[N,5], pk u64[N,4] little-endian limbs)"""
+    n = len(lines)
+    comp = np.zeros(n, np.uint8)
+    h = np.zeros((n, 5), np.uint32)
+    pk = np.zeros((n, 4), np.uint64)
+    for i, l in enumerate(lines):
+        label, hh, kk = l.split("\t")
+        comp[i] = 1 if label == "addr33" else 0
+        h[i] = [int(hh[8 * j : 8 * j + 8], 16) for j in range(5)]
+        v = int(kk, 16)
+        pk[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    return comp, h, pk
+
+
+def status_counts(status):
+    # "3.25s ~ 2.58 Mkeys/s ~ 1 / 8,388,608"
+    tail = status.split("~")[-1]
+    found, checked = tail.split("/")
+    clean = lambda s: int("".join(ch for ch in s if ch.isdigit()))
+    return clean(found), clean(checked)
+
+
+def main():
+    g = {"reference": "vladkens/ecloop v0.5.0, built by oracle/Makefile `ref`", "cases": {}}
+    tmp = tempfile.mkdtemp()
+    ones = os.path.join(tmp, "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+
+    def case(name, args, store="npz", stdin_path=None):
+        stdin = open(stdin_path, "rb") if stdin_path else None
+        lines, status = run_ref(args, stdin)
+        found, checked = status_counts(status)
+        entry = {"args": args, "count": len(lines), "status_found": found, "status_checked": checked,
+                 "sha256_sorted": digest(lines)}
+        if stdin_path:
+            entry["stdin"] = stdin_path
+        if store == "npz":
+            comp, h, pk = parse(lines)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), compressed=comp, h160=h, pk=pk)
+            entry["npz"] = name + ".npz"
+        elif store == "lines":
+            entry["lines"] = lines
+        elif store == "head":
+            entry["head"] = lines[:64]
+        g["cases"][name] = entry
+        print(f"{name}: {len(lines)} lines, status {found} / {checked}")
+
+    puzzles = os.path.join(REF_DATA, "btc-puzzles-hash")
+    # --- known-answer flows of the reference
+    case("cfg1_list_800000_ffffff", ["add", "-f", puzzles, "-r", "800000:ffffff", "-t", "1"], "lines")
+    case("make_add_8000_ffffff", ["add", "-f", puzzles, "-r", "8000:ffffff", "-t", "1"], "lines")
+    case("ci_smoke_8000_ffff", ["add", "-f", puzzles, "-r", "8000:ffff", "-t", "1"], "lines")
+    case("endo_cu_list_8000_fffff", ["add", "-f", puzzles, "-r", "8000:fffff", "-t", "1", "-a", "cu", "-endo"], "lines")
+    case("make_mul_bw", ["mul", "-f", os.path.join(REF_DATA, "btc-bw-hash"), "-t", "1", "-a", "cu"], "head",
+         stdin_path=os.path.join(REF_DATA, "btc-bw-priv"))
+    # --- per-key dumps through the all-ones bloom
+    case("dump33_8000_87ff", ["add", "-f", ones, "-r", "8000:87ff", "-t", "1"], "npz")
+    case("dump65_8000_87ff", ["add", "-f", ones, "-r", "8000:87ff", "-t", "1", "-a", "u"], "npz")
+    case("dump_cu_endo_8000_87ff", ["add", "-f", ones, "-r", "8000:87ff", "-t", "1", "-a", "cu", "-endo"], "head")
+    # strided: one key wide range, 2048 keys spaced 2^128; range end is 165 bits so ord_offs is not clamped
+    a = 1 << 164
+    case("dump33_stride128", ["add", "-f", ones, "-r", f"{a + 0x12345:x}:{a + 0x12346:x}", "-d", "128:32", "-t", "1"], "npz")
+    # range that is not a multiple of 2048 and overruns its end (QUIRK main.c:442 + 368)
+    case("dump33_overrun_9000_9801", ["add", "-f", ones, "-r", "9000:9801", "-t", "1"], "npz")
+    # mul KAT: stdin "1" -> hash160 of G, both encodings
+    one = os.path.join(tmp, "one.txt")
+    open(one, "w").write("1\n")
+    case("mul_G", ["mul", "-f", ones, "-t", "1", "-a", "cu"], "lines", stdin_path=one)
+    # mul over seeded scalars of assorted sizes (all-ones dump)
+    import random
+    rnd = random.Random(20250929)
+    n_ = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    ks = [2, 3, 0x3FFF, 0x4000, 0x4001, n_ - 1, n_ - 2, (1 << 255) + 12345]
+    ks += [rnd.randrange(1, 1 << rnd.choice([8, 14, 28, 64, 128, 200, 256])) % n_ or 5 for _ in range(248)]
+    mul_in = os.path.join(HERE, "mul_scalars.txt")
+    open(mul_in, "w").write("".join(f"{k:x}\n" for k in ks))
+    case("mul_dump_cu", ["mul", "-f", ones, "-t", "1", "-a", "cu"], "npz", stdin_path=mul_in)
+    g["cases"]["mul_dump_cu"]["stdin"] = "tests/golden/mul_scalars.txt"
+    # --- sparse synthetic bloom: false positives pin the probe order / modulus (non power-of-two size)
+    sp = os.path.join(tmp, "sparse.blf")
+    write_blf(sp, synth_bloom_words(12345, seed=7, mode="a|(b&c)"))
+    case("sparse_fp33_two_jobs", ["add", "-f", sp, "-r", "8000:208800", "-t", "1"], "npz")
+    g["cases"]["sparse_fp33_two_jobs"]["bloom"] = {"words": 12345, "seed": 7, "mode": "a|(b&c)"}
+    dn = os.path.join(tmp, "dense.blf")
+    write_blf(dn, synth_bloom_words(4099, seed=11, mode="a|b"))
+    case("dense_fp_cu_endo", ["add", "-f", dn, "-r", "8000:87ff", "-t", "1", "-a", "cu", "-endo"], "npz")
+    g["cases"]["dense_fp_cu_endo"]["bloom"] = {"words": 4099, "seed": 11, "mode": "a|b"}
+    # --- blf-gen bytes from the puzzles list (comment-free input)
+    blf_out = os.path.join(tmp, "puz.blf")
+    subprocess.run([ref_bin(), "blf-gen", "-n", "32768", "-o", blf_out], stdin=open(puzzles, "rb"),
+                   stdout=subprocess.DEVNULL, check=True)
+    raw = open(blf_out, "rb").read()
+    g["cases"]["blf_gen_puzzles_32768"] = {"bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest(),
+                                           "header_hex": raw[:16].hex(), "size_words": struct.unpack("<Q", raw[8:16])[0]}
+    # inputs owned by the reference's data/ directory: stored as data fixtures for the GPU box
+    for name in ("btc-puzzles-hash", "btc-bw-hash", "btc-bw-priv"):
+        dst = os.path.join(HERE, name)
+        open(dst, "wb").write(open(os.path.join(REF_DATA, name), "rb").read())
+    json.dump(g, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()
