@@ -1,0 +1,48 @@
+"""Builds the gfx950 shared library in-tree: ecloop_amd/libecloop_hip.so (hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libecloop_hip.so")
+SOURCES = ["ecloop_hip.hip", "add_kernel.h", "hash160.h", "fe256.h", "ec.h", "bloom.h", "scalar_host.h"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, "include", "ecloop_hip.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           os.path.join(CSRC, "ecloop_hip.hip"), "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_host_cli(force=False):
+    """The C host program (ecloop-hip): plain C, links the C ABI only."""
+    src = os.path.join(PKG, "host", "ecloop_hip_cli.c")
+    out = os.path.join(PKG, "host", "ecloop-hip")
+    if not os.path.exists(src):
+        return None
+    if not force and not _stale(out, [src, os.path.join(ROOT, "include", "ecloop_hip.h")]):
+        return out
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out,
+                    "-L", PKG, "-lecloop_hip", "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lm"], check=True)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))
+    print(build_host_cli(force=True))

@@ -1,0 +1,169 @@
+"""ctypes binding of the C ABI in include/ecloop_hip.h (libecloop_hip.so, built in-tree by ecloop_amd.build).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libecloop_hip.so")
+
+ADDR33, ADDR65, ENDO = 1, 2, 4
+E_OVERFLOW = -4
+
+U64x4 = C.c_uint64 * 4
+
+
+class Found(C.Structure):
+    _fields_ = [("key_offset", C.c_uint64), ("h160", C.c_uint32 * 5), ("endo", C.c_uint8),
+                ("compressed", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+FOUND_DTYPE = np.dtype([("key_offset", "<u8"), ("h160", "<u4", (5,)), ("endo", "u1"), ("compressed", "u1"),
+                        ("pad", "u1", (2,))])
+assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
+
+EXPORTS = [
+    "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_add_range",
+    "ecl_hip_mul_batch", "ecl_hip_set_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
+    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
+]
+
+_lib = None
+
+
+class EclError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EclError(f"{LIB_PATH} is missing: build it with `python -m ecloop_amd.build` "
+                       "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.ecl_hip_device_count.restype = C.c_int
+    lib.ecl_hip_open.argtypes = [C.POINTER(P), C.c_int, C.c_uint32, C.c_uint32]
+    lib.ecl_hip_close.argtypes = [P]
+    lib.ecl_hip_close.restype = None
+    lib.ecl_hip_set_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
+    lib.ecl_hip_add_range.argtypes = [P, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ecl_hip_mul_batch.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ecl_hip_set_geometry.argtypes = [P, C.c_uint32, C.c_uint32]
+    lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ecl_hip_reset_timing.argtypes = [P]
+    lib.ecl_hip_strerror.argtypes = [C.c_int]
+    lib.ecl_hip_strerror.restype = C.c_char_p
+    lib.ecl_hip_last_error.argtypes = [P]
+    lib.ecl_hip_last_error.restype = C.c_char_p
+    lib.ecl_hip_diag_fe.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ecl_hip_diag_mulg.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ecl_hip_diag_hash160.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ecl_hip_diag_bloom.argtypes = [P, C.c_void_p, C.c_void_p, C.c_uint32]
+    _lib = lib
+    return lib
+
+
+def limbs(v):
+    """python int -> 4 little-endian u64 limbs (the reference's `fe`)"""
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def limbs_array(vals):
+    return np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64).reshape(-1, 4)
+
+
+def ints_of(arr):
+    return [sum(int(r[i]) << (64 * i) for i in range(4)) for r in arr]
+
+
+class Device:
+    """One GPU context (ecl_hip handle)."""
+
+    def __init__(self, device=0, a33=True, a65=False, endo=False, ord_offs=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        flags = (ADDR33 if a33 else 0) | (ADDR65 if a65 else 0) | (ENDO if endo else 0)
+        rc = self.lib.ecl_hip_open(C.byref(self.h), device, flags, ord_offs)
+        if rc != 0:
+            msg = self.lib.ecl_hip_last_error(self.h).decode() if self.h else ""
+            if self.h:
+                self.lib.ecl_hip_close(self.h)
+                self.h = None
+            raise EclError(f"ecl_hip_open(device={device}): {self.lib.ecl_hip_strerror(rc).decode()} {msg}")
+
+    def _chk(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise EclError(f"{self.lib.ecl_hip_strerror(rc).decode()}: {self.lib.ecl_hip_last_error(self.h).decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ecl_hip_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_bloom(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        self._chk(self.lib.ecl_hip_set_bloom(self.h, w.ctypes.data, len(w)))
+
+    def set_geometry(self, half_group=0, max_lanes=0):
+        self._chk(self.lib.ecl_hip_set_geometry(self.h, half_group, max_lanes))
+
+    def add_range(self, start, nkeys, cap=4096):
+        """-> (records as numpy structured array, total hit count). Raises on overflow unless total <= cap."""
+        out = np.zeros(cap, dtype=FOUND_DTYPE)
+        n = C.c_uint32()
+        s = limbs(start)
+        rc = self.lib.ecl_hip_add_range(self.h, s.ctypes.data, nkeys, out.ctypes.data, cap, C.byref(n))
+        self._chk(rc, allow=(E_OVERFLOW,))
+        return out[: min(n.value, cap)], n.value
+
+    def mul_batch(self, scalars, cap=4096):
+        k = limbs_array(scalars)
+        out = np.zeros(cap, dtype=FOUND_DTYPE)
+        n = C.c_uint32()
+        rc = self.lib.ecl_hip_mul_batch(self.h, k.ctypes.data, len(k), out.ctypes.data, cap, C.byref(n))
+        self._chk(rc, allow=(E_OVERFLOW,))
+        return out[: min(n.value, cap)], n.value
+
+    def timing(self):
+        ms, launches, keys = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.ecl_hip_get_timing(self.h, C.byref(ms), C.byref(launches), C.byref(keys)))
+        return ms.value, launches.value, keys.value
+
+    def reset_timing(self):
+        self._chk(self.lib.ecl_hip_reset_timing(self.h))
+
+    # ---- diagnostics
+    def diag_fe(self, op, a, b=None):
+        A = limbs_array(a)
+        Bv = limbs_array(b) if b is not None else A
+        R = np.zeros_like(A)
+        self._chk(self.lib.ecl_hip_diag_fe(self.h, op, A.ctypes.data, Bv.ctypes.data, R.ctypes.data, len(A)))
+        return ints_of(R)
+
+    def diag_mulg(self, ks):
+        K = limbs_array(ks)
+        X, Y = np.zeros_like(K), np.zeros_like(K)
+        ok = np.zeros(len(K), dtype=np.uint8)
+        self._chk(self.lib.ecl_hip_diag_mulg(self.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, len(K)))
+        return ints_of(X), ints_of(Y), ok
+
+    def diag_hash160(self, xs, ys):
+        X, Y = limbs_array(xs), limbs_array(ys)
+        h33 = np.zeros((len(X), 5), dtype=np.uint32)
+        h65 = np.zeros((len(X), 5), dtype=np.uint32)
+        self._chk(self.lib.ecl_hip_diag_hash160(self.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, len(X)))
+        return h33, h65
+
+    def diag_bloom(self, hashes):
+        H = np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)
+        hit = np.zeros(len(H), dtype=np.uint8)
+        self._chk(self.lib.ecl_hip_diag_bloom(self.h, H.ctypes.data, hit.ctypes.data, len(H)))
+        return hit

@@ -1,0 +1,69 @@
+// bloom.h — probe of the reference's bloom filter (lib/utils.c:274-326), bit-compatible with `.blf` files.
+//
+// 20 probe positions per hash160: five overlapping 64-bit words a1..a5 of the hash, for S in {24,28,36,40}
+// and j = 1..5: idx = a_j << S | a_{j+1} >> S (a6 = a1); bit (idx mod 64) of word ((idx mod 64*size) / 64)
+// = word ((idx >> 6) mod size).  `size` is arbitrary (not a power of two), so the modulo uses a host
+// precomputed reciprocal (one 64x64 high multiply + one low multiply) instead of a 64-bit division.
+// Probe order (S outer, j inner) and the early-out on the first zero bit follow lib/utils.c:308-326.
+#pragma once
+#include "fe256.h"
+
+struct bloom_t {
+  const u64* bits;
+  u64 nwords;
+  u64 recip;  // floor(2^64 / nwords) for nwords >= 2 (unused for nwords == 1)
+};
+
+FE_FN u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+__host__ __device__ inline bloom_t bloom_make(const u64* bits, u64 nwords) {
+  bloom_t b;
+  b.bits = bits, b.nwords = nwords;
+  b.recip = nwords >= 2 ? (u64)((((unsigned __int128)1) << 64) / nwords) : 0;
+  return b;
+}
+// x mod nwords for x < 2^58
+FE_FN u64 bloom_mod(const bloom_t& b, u64 x) {
+  u64 q = mulhi64(x, b.recip);  // q in {floor(x/d) - 1, floor(x/d)}; for d == 1 recip = 0 -> q = 0
+  u64 r = x - q * b.nwords;
+  if (r >= b.nwords) r -= b.nwords;
+  if (r >= b.nwords) r -= b.nwords;
+  if (b.nwords == 1) r = 0;
+  return r;
+}
+FE_FN u64 bloom_index(const u64 a[5], int probe) {
+  const int S = probe < 5 ? 24 : probe < 10 ? 28 : probe < 15 ? 36 : 40;
+  const int j = probe % 5;
+  return a[j] << S | a[(j + 1) % 5] >> S;
+}
+FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (b.bits[bloom_mod(b, idx >> 6)] >> (idx & 63)) & 1; }
+
+// lib/utils.c:308-326. The first two probes are issued together (independent loads), the remaining 18 only
+// by lanes that passed both, one at a time with early-out.
+FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) {
+  u64 a[5];
+  a[0] = (u64)h[0] << 32 | h[1];
+  a[1] = (u64)h[2] << 32 | h[3];
+  a[2] = (u64)h[4] << 32 | h[0];
+  a[3] = (u64)h[1] << 32 | h[2];
+  a[4] = (u64)h[3] << 32 | h[4];
+  bool p0 = bloom_bit(b, bloom_index(a, 0));
+  bool p1 = bloom_bit(b, bloom_index(a, 1));
+  if (!(p0 && p1)) return false;
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    const int S = s == 0 ? 24 : s == 1 ? 28 : s == 2 ? 36 : 40;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {  // unrolled: a[] must stay in registers (no runtime indexing)
+      if (s == 0 && j < 2) continue;
+      u64 idx = a[j] << S | a[(j + 1) % 5] >> S;
+      if (!bloom_bit(b, idx)) return false;
+    }
+  }
+  return true;
+}

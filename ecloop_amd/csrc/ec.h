@@ -1,0 +1,85 @@
+// ec.h — secp256k1 group operations for the set-up kernels (start points, table points, `mul` command).
+//
+// The reference's curve layer (lib/ecc.c:611-929) uses homogeneous projective formulas without any handling
+// of the exceptional cases (it asserts, lib/ecc.c:666).  The hot loop never needs a general addition (see
+// add_kernel.h: affine + affine with a batched inverse), so the general code here only serves the per-launch
+// set-up and the `mul` path.  It is written for robustness: Jacobian coordinates, mixed addition with the
+// doubling / inverse / infinity cases handled, results always returned as canonical affine coordinates, which
+// is all that reaches the hash (an affine point is unique, so parity with lib/ecc.c is by value).
+#pragma once
+#include "fe256.h"
+
+struct jac {
+  fe X, Y, Z;
+  u32 inf;  // 1 = point at infinity
+};
+
+FE_FN fe fe_dbl(const fe& a) { return fe_add(a, a); }
+
+// 2P, a = 0 curve: 2M + 5S ("dbl-2009-l")
+FE_FN jac jac_dbl(const jac& p) {
+  jac r;
+  r.inf = p.inf;
+  fe A = fe_sqr(p.X), B = fe_sqr(p.Y), C = fe_sqr(B);
+  fe t = fe_sqr(fe_add(p.X, B));
+  fe D = fe_dbl(fe_sub(fe_sub(t, A), C));
+  fe E = fe_add(fe_dbl(A), A);
+  fe F = fe_sqr(E);
+  r.X = fe_sub(F, fe_dbl(D));
+  fe C8 = fe_dbl(fe_dbl(fe_dbl(C)));
+  r.Y = fe_sub(fe_mul(E, fe_sub(D, r.X)), C8);
+  r.Z = fe_dbl(fe_mul(p.Y, p.Z));
+  return r;
+}
+
+// P + (qx, qy) with Q affine and finite. Complete: handles P = inf, P = Q (doubling), P = -Q (infinity).
+FE_FN jac jac_madd(const jac& p, const fe& qx, const fe& qy) {
+  if (p.inf) {
+    jac r;
+    r.X = qx, r.Y = qy, r.Z = fe_one(), r.inf = 0;
+    return r;
+  }
+  fe zz = fe_sqr(p.Z);
+  fe u2 = fe_mul(qx, zz);
+  fe s2 = fe_mul(qy, fe_mul(zz, p.Z));
+  fe h = fe_sub(u2, p.X);
+  fe rr = fe_sub(s2, p.Y);
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return jac_dbl(p);
+    jac r = p;
+    r.inf = 1;
+    return r;
+  }
+  fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(p.X, hh);
+  jac r;
+  r.inf = 0;
+  r.X = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_dbl(v));
+  r.Y = fe_sub(fe_mul(rr, fe_sub(v, r.X)), fe_mul(p.Y, hhh));
+  r.Z = fe_mul(p.Z, h);
+  return r;
+}
+
+// Jacobian -> affine (x = X/Z^2, y = Y/Z^3); returns 0 for the point at infinity
+FE_FN int jac_to_affine(fe& x, fe& y, const jac& p) {
+  if (p.inf) {
+    x = fe_zero(), y = fe_zero();
+    return 0;
+  }
+  fe zi = fe_inv(p.Z), zi2 = fe_sqr(zi);
+  x = fe_mul(p.X, zi2);
+  y = fe_mul(p.Y, fe_mul(zi2, zi));
+  return 1;
+}
+
+// k*G, MSB-first double-and-add (the reference's ec_jacobi_mulrdc(&G1, k), lib/ecc.c:821-853, by value)
+__host__ __device__ __noinline__ inline int ec_mul_g_affine(fe& x, fe& y, const u32 k[8]) {
+  const fe gx = FE_GX, gy = FE_GY;
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#pragma unroll 1
+  for (int bit = 255; bit >= 0; --bit) {
+    if (!acc.inf) acc = jac_dbl(acc);
+    if ((k[bit >> 5] >> (bit & 31)) & 1u) acc = jac_madd(acc, gx, gy);
+  }
+  return jac_to_affine(x, y, acc);
+}

@@ -1,0 +1,510 @@
+// ecloop_hip.hip — kernels' instantiation + the C ABI of include/ecloop_hip.h (host side, HIP runtime).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ecloop_hip.hip -o libecloop_hip.so
+#include "../../include/ecloop_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "add_kernel.h"
+#include "ec.h"
+#include "scalar_host.h"
+
+// ------------------------------------------------------------------------------------------------ set-up kernels
+
+// affine public keys of n scalars: out[i] = {x[8], y[8]} (canonical), ok[i] = 0 for infinity
+__global__ void __launch_bounds__(64) k_mul_g(const u32* __restrict__ k, u32* __restrict__ out, u8* __restrict__ ok, u32 n) {
+  u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  u32 kk[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
+  fe x, y;
+  int fin = ec_mul_g_affine(x, y, kk);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) out[(size_t)i * 16 + w] = x.v[w], out[(size_t)i * 16 + 8 + w] = y.v[w];
+  if (ok) ok[i] = (u8)fin;
+}
+
+// lane centres C_g = C_0 + g*D from the ladder {2^j * D}: at most 32 mixed additions + one inversion per lane
+__global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0, const u32* __restrict__ ladder,
+                                                       uint4* __restrict__ cxy, u32 T) {
+  u32 g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= T) return;
+  jac acc;
+  acc.X = fe_ldw(c0), acc.Y = fe_ldw(c0 + 8), acc.Z = fe_one(), acc.inf = 0;
+#pragma unroll 1
+  for (int j = 0; j < 32; ++j) {
+    if ((g >> j) == 0) break;
+    if ((g >> j) & 1u) acc = jac_madd(acc, fe_ldw(ladder + j * 16), fe_ldw(ladder + j * 16 + 8));
+  }
+  fe x, y;
+  jac_to_affine(x, y, acc);
+  fe_st2(cxy + g, T, x);
+  fe_st2(cxy + 2 * (size_t)T + g, T, y);
+}
+
+// `mul` command body: public key of each scalar, hash, probe (main.c:530-534, 458-479)
+template <bool A33, bool A65>
+__global__ void __launch_bounds__(64) k_mul_check(const u32* __restrict__ k, u32 n, add_args a) {
+  u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  u32 kk[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
+  fe x, y;
+  if (!ec_mul_g_affine(x, y, kk)) return;
+  check_point<A33, A65, false>(a, x, y, (u64)i);
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+__global__ void k_diag_fe(int op, const u32* a, const u32* b, u32* r, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_ldw(a + (size_t)i * 8), y = fe_ldw(b + (size_t)i * 8), z;
+  switch (op) {
+  case 0: z = fe_mul(x, y); break;
+  case 1: z = fe_sqr(x); break;
+  case 2: z = fe_inv(x); break;
+  case 3: z = fe_sub(x, y); break;
+  case 4: z = fe_add(x, y); break;
+  default: z = fe_neg(x); break;
+  }
+#pragma unroll
+  for (int w = 0; w < 8; ++w) r[(size_t)i * 8 + w] = z.v[w];
+}
+__global__ void k_diag_hash(const u32* x, const u32* y, u32* h33, u32* h65, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe fx = fe_ldw(x + (size_t)i * 8), fy = fe_ldw(y + (size_t)i * 8);
+  u32 h[5];
+  hash160_33(h, fx, fy.v[0] & 1u);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h33[(size_t)i * 5 + w] = h[w];
+  hash160_65(h, fx, fy);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h65[(size_t)i * 5 + w] = h[w];
+}
+__global__ void k_diag_bloom(bloom_t b, const u32* h160, u8* hit, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 h[5];
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h[w] = h160[(size_t)i * 5 + w];
+  hit[i] = bloom_has(b, h) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ context
+
+struct ecl_hip {
+  int dev = 0;
+  u32 flags = 0, offs = 0;
+  u32 B = 1024;       // table points per group
+  u32 Tmax = 0;       // lanes walked concurrently (0 = derive from occupancy)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // device buffers
+  u32* d_tab = nullptr;  u32 tab_B = 0;        // table for (B, offs)
+  u32* d_aux = nullptr;                        // [0]=C0, [1]=jump, [2..33]=ladder : 34 points x 16 words
+  u32* d_auxk = nullptr;                       // scalars for the above
+  uint4* d_cxy = nullptr; size_t cxy_T = 0;
+  uint4* d_scr = nullptr; size_t scr_elems = 0;
+  u64* d_bloom = nullptr; u64 bloom_words = 0;
+  ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
+  u32* d_counter = nullptr;
+  // walk state for contiguous continuation
+  bool walk_valid = false;
+  u32 walk_T = 0;
+  u256 walk_next;  // scalar (mod n) the resident centres are positioned for
+  u32 jump_host[16];
+  // timing
+  double kernel_ms = 0;
+  uint64_t launches = 0, keys = 0;
+};
+
+#define HIPCHK(h, call)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return ECL_E_HIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+static void words_of(u32 w[8], const u256& a) {
+  for (int i = 0; i < 4; ++i) w[2 * i] = (u32)a.w[i], w[2 * i + 1] = (u32)(a.w[i] >> 32);
+}
+
+extern "C" {
+
+int ecl_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* ecl_hip_strerror(int code) {
+  switch (code) {
+  case ECL_OK: return "ok";
+  case ECL_E_ARG: return "bad argument";
+  case ECL_E_HIP: return "HIP runtime error";
+  case ECL_E_NODEV: return "no such GPU";
+  case ECL_E_OVERFLOW: return "more hits than the output buffer holds";
+  case ECL_E_NOBLOOM: return "no bloom filter set";
+  case ECL_E_RANGE: return "range touches scalar 0 (mod n)";
+  default: return "unknown error";
+  }
+}
+const char* ecl_hip_last_error(const ecl_hip* h) { return h ? h->err.c_str() : ""; }
+
+int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
+  if (!out || ord_offs > 255 || !(flags & (ECL_ADDR33 | ECL_ADDR65)) || (flags & ~7u)) return ECL_E_ARG;
+  int n = ecl_hip_device_count();
+  if (device < 0 || device >= n) return ECL_E_NODEV;
+  ecl_hip* h = new ecl_hip();
+  h->dev = device, h->flags = flags, h->offs = ord_offs;
+  *out = h;
+  HIPCHK(h, hipSetDevice(device));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreate(&h->ev0));
+  HIPCHK(h, hipEventCreate(&h->ev1));
+  HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_counter, sizeof(u32)));
+  return ECL_OK;
+}
+
+void ecl_hip_close(ecl_hip* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->dev);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->d_tab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
+  (void)hipFree(h->d_scr), (void)hipFree(h->d_bloom), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
+  if (!h || !bits || nwords == 0 || nwords >= (1ull << 58)) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->d_bloom) HIPCHK(h, hipFree(h->d_bloom));
+  h->d_bloom = nullptr, h->bloom_words = 0;
+  HIPCHK(h, hipMalloc(&h->d_bloom, nwords * sizeof(u64)));
+  HIPCHK(h, hipMemcpy(h->d_bloom, bits, nwords * sizeof(u64), hipMemcpyHostToDevice));
+  h->bloom_words = nwords;
+  return ECL_OK;
+}
+
+int ecl_hip_set_geometry(ecl_hip* h, uint32_t half_group, uint32_t max_lanes) {
+  if (!h) return ECL_E_ARG;
+  if (half_group) {
+    if (half_group < 2 || half_group > (1u << 16)) return ECL_E_ARG;
+    h->B = half_group;
+  }
+  if (max_lanes) h->Tmax = (max_lanes + 255u) & ~255u;
+  h->walk_valid = false;
+  return ECL_OK;
+}
+
+int ecl_hip_get_timing(ecl_hip* h, double* kernel_ms, uint64_t* launches, uint64_t* keys) {
+  if (!h) return ECL_E_ARG;
+  if (kernel_ms) *kernel_ms = h->kernel_ms;
+  if (launches) *launches = h->launches;
+  if (keys) *keys = h->keys;
+  return ECL_OK;
+}
+int ecl_hip_reset_timing(ecl_hip* h) {
+  if (!h) return ECL_E_ARG;
+  h->kernel_ms = 0, h->launches = 0, h->keys = 0;
+  return ECL_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ add path (host)
+
+typedef void (*add_kernel_t)(const add_args);
+static add_kernel_t pick_add_kernel(u32 flags) {
+  bool a33 = flags & ECL_ADDR33, a65 = flags & ECL_ADDR65, endo = flags & ECL_ENDO;
+  if (a33 && !a65) return endo ? k_add<true, false, true> : k_add<true, false, false>;
+  if (!a33 && a65) return endo ? k_add<false, true, true> : k_add<false, true, false>;
+  return endo ? k_add<true, true, true> : k_add<true, true, false>;
+}
+
+static int ensure_found(ecl_hip* h, u32 cap) {
+  if (cap <= h->found_cap) return ECL_OK;
+  if (h->d_found) HIPCHK(h, hipFree(h->d_found));
+  h->d_found = nullptr, h->found_cap = 0;
+  HIPCHK(h, hipMalloc(&h->d_found, (size_t)cap * sizeof(ecl_found_dev)));
+  h->found_cap = cap;
+  return ECL_OK;
+}
+
+static int default_lanes(ecl_hip* h) {
+  if (h->Tmax) return ECL_OK;
+  hipDeviceProp_t p;
+  HIPCHK(h, hipGetDeviceProperties(&p, h->dev));
+  int occ = 0;
+  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)pick_add_kernel(h->flags), 256, 0));
+  if (occ < 1) occ = 1;
+  h->Tmax = (u32)p.multiProcessorCount * (u32)occ * 256u;
+  return ECL_OK;
+}
+
+// table of (i+1)*stride*G, i < B (ctx_precompute_gpoints, main.c:219-246: only x,y of the positive half are stored)
+static int ensure_table(ecl_hip* h) {
+  if (h->d_tab && h->tab_B == h->B) return ECL_OK;
+  if (h->d_tab) HIPCHK(h, hipFree(h->d_tab));
+  h->d_tab = nullptr;
+  const u32 B = h->B;
+  std::vector<u32> ks((size_t)B * 8);
+  u256 s = sc_pow2(h->offs), cur = s;
+  for (u32 i = 0; i < B; ++i) {
+    words_of(&ks[(size_t)i * 8], cur);
+    cur = sc_add(cur, s);
+  }
+  u32* d_k = nullptr;
+  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_tab, (size_t)B * 16 * sizeof(u32)));
+  HIPCHK(h, hipMemcpyAsync(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_mul_g, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_k, h->d_tab, (u8*)nullptr, B);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(d_k));
+  h->tab_B = B;
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
+                                 uint32_t* nout) {
+  if (!h || !start || (!out && cap) || !nout) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (nkeys == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = default_lanes(h)) != ECL_OK) return rc;
+  if ((rc = ensure_table(h)) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, cap ? cap : 1)) != ECL_OK) return rc;
+
+  const u32 B = h->B;
+  const u64 group = 2ull * B;
+  u64 ngroups = (nkeys + group - 1) / group;
+  u32 T = (u32)((ngroups < h->Tmax ? ngroups : h->Tmax) + 255) & ~255u;
+  if (T > h->Tmax) T = h->Tmax;
+  u32 nb = (u32)((ngroups + T - 1) / T);
+
+  u256 k0 = sc_reduce(u256_from(start));
+  const u256 s = sc_pow2(h->offs);
+  bool cont = h->walk_valid && h->walk_T == T && u256_eq(h->walk_next, k0);
+  if (!cont) {
+    // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G
+    u256 d = sc_mul_u64(s, group);
+    std::vector<u32> ks(34 * 8);
+    words_of(&ks[0], sc_add(k0, sc_mul_u64(s, B)));
+    words_of(&ks[8], sc_mul_u64(d, T));
+    u256 l = d;
+    for (int j = 0; j < 32; ++j) {
+      words_of(&ks[(size_t)(2 + j) * 8], l);
+      l = sc_add(l, l);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_auxk, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_mul_g, dim3(1), dim3(64), 0, h->stream, h->d_auxk, h->d_aux, (u8*)nullptr, 34u);
+    HIPCHK(h, hipGetLastError());
+    if (h->cxy_T < T) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (h->d_cxy) HIPCHK(h, hipFree(h->d_cxy));
+      h->d_cxy = nullptr, h->cxy_T = 0;
+      HIPCHK(h, hipMalloc(&h->d_cxy, (size_t)T * 4 * sizeof(uint4)));
+      h->cxy_T = T;
+    }
+    hipLaunchKernelGGL(k_init_centres, dim3(T / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32, h->d_cxy, T);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->walk_T = T;
+  }
+  size_t need = (size_t)T * B * 2;
+  if (h->scr_elems < need) {
+    if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
+    h->d_scr = nullptr, h->scr_elems = 0;
+    HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
+    h->scr_elems = need;
+  }
+
+  add_args a;
+  a.tab = h->d_tab;
+  memcpy(a.jump, h->jump_host, sizeof a.jump);
+  a.cxy = h->d_cxy, a.scratch = h->d_scr;
+  a.bloom = bloom_make(h->d_bloom, h->bloom_words);
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
+  a.B = B, a.T = T, a.nb = nb, a.nkeys = nkeys;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(u32), h->stream));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(pick_add_kernel(h->flags), dim3(T / 256), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  u32 cnt = 0;
+  HIPCHK(h, hipMemcpyAsync(&cnt, h->d_counter, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->kernel_ms += ms, h->launches += 1, h->keys += nkeys;
+
+  // the centres now sit at the start of group nb*T + g: valid continuation only if the launch was exact
+  const u64 walked = (u64)nb * T * group;
+  h->walk_valid = walked == nkeys;
+  if (h->walk_valid) h->walk_next = sc_add(k0, sc_mul_u64(s, walked));
+
+  u32 take = cnt < cap ? cnt : cap;
+  if (take) {
+    std::vector<ecl_found_dev> tmp(take);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < take; ++i) {
+      out[i].key_offset = tmp[i].key_offset;
+      memcpy(out[i].h160, tmp[i].h160, 20);
+      out[i].endo = (uint8_t)(tmp[i].tag & 0xff), out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
+      out[i].pad[0] = out[i].pad[1] = 0;
+    }
+  }
+  *nout = cnt;
+  return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
+}
+
+extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
+                                 uint32_t* nout) {
+  if (!h || (!scalars && n) || (!out && cap) || !nout) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = ensure_found(h, cap ? cap : 1)) != ECL_OK) return rc;
+  std::vector<u32> ks((size_t)n * 8);
+  for (u32 i = 0; i < n; ++i) words_of(&ks[(size_t)i * 8], sc_reduce(u256_from(scalars[i])));
+  u32* d_k = nullptr;
+  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMemcpyAsync(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  add_args a;
+  memset(&a, 0, sizeof a);
+  a.bloom = bloom_make(h->d_bloom, h->bloom_words);
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(u32), h->stream));
+  bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+  dim3 grid((n + 63) / 64), blk(64);
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, n, a);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, n, a);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, n, a);
+  HIPCHK(h, hipGetLastError());
+  u32 cnt = 0;
+  HIPCHK(h, hipMemcpyAsync(&cnt, h->d_counter, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(d_k));
+  u32 take = cnt < cap ? cnt : cap;
+  if (take) {
+    std::vector<ecl_found_dev> tmp(take);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < take; ++i) {
+      out[i].key_offset = tmp[i].key_offset;
+      memcpy(out[i].h160, tmp[i].h160, 20);
+      out[i].endo = 0, out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
+      out[i].pad[0] = out[i].pad[1] = 0;
+    }
+  }
+  *nout = cnt;
+  return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics (host)
+
+template <typename T>
+struct dbuf {
+  T* p = nullptr;
+  ~dbuf() { if (p) (void)hipFree(p); }
+};
+
+extern "C" int ecl_hip_diag_fe(ecl_hip* h, int op, const uint64_t (*a)[4], const uint64_t (*b)[4], uint64_t (*r)[4],
+                               uint32_t n) {
+  if (!h || !a || !r || n == 0 || op < 0 || op > 5) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  size_t bytes = (size_t)n * 32;
+  dbuf<u32> da, db, dr;
+  HIPCHK(h, hipMalloc(&da.p, bytes));
+  HIPCHK(h, hipMalloc(&db.p, bytes));
+  HIPCHK(h, hipMalloc(&dr.p, bytes));
+  HIPCHK(h, hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));  // little-endian u64 limbs == u32 word pairs
+  HIPCHK(h, hipMemcpy(db.p, b ? b : a, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_diag_fe, dim3((n + 63) / 64), dim3(64), 0, h->stream, op, da.p, db.p, dr.p, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(r, dr.p, bytes, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_diag_mulg(ecl_hip* h, const uint64_t (*k)[4], uint64_t (*x)[4], uint64_t (*y)[4], uint8_t* ok,
+                                 uint32_t n) {
+  if (!h || !k || !x || !y || n == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  dbuf<u32> dk, dout;
+  dbuf<u8> dok;
+  HIPCHK(h, hipMalloc(&dk.p, (size_t)n * 32));
+  HIPCHK(h, hipMalloc(&dout.p, (size_t)n * 64));
+  HIPCHK(h, hipMalloc(&dok.p, n));
+  HIPCHK(h, hipMemcpy(dk.p, k, (size_t)n * 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_mul_g, dim3((n + 63) / 64), dim3(64), 0, h->stream, dk.p, dout.p, dok.p, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<u32> o((size_t)n * 16);
+  std::vector<u8> okv(n);
+  HIPCHK(h, hipMemcpy(o.data(), dout.p, (size_t)n * 64, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(okv.data(), dok.p, n, hipMemcpyDeviceToHost));
+  for (u32 i = 0; i < n; ++i) {
+    memcpy(x[i], &o[(size_t)i * 16], 32);
+    memcpy(y[i], &o[(size_t)i * 16 + 8], 32);
+    if (ok) ok[i] = okv[i];
+  }
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_diag_hash160(ecl_hip* h, const uint64_t (*x)[4], const uint64_t (*y)[4], uint32_t (*h33)[5],
+                                    uint32_t (*h65)[5], uint32_t n) {
+  if (!h || !x || !y || !h33 || !h65 || n == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  dbuf<u32> dx, dy, d33, d65;
+  HIPCHK(h, hipMalloc(&dx.p, (size_t)n * 32));
+  HIPCHK(h, hipMalloc(&dy.p, (size_t)n * 32));
+  HIPCHK(h, hipMalloc(&d33.p, (size_t)n * 20));
+  HIPCHK(h, hipMalloc(&d65.p, (size_t)n * 20));
+  HIPCHK(h, hipMemcpy(dx.p, x, (size_t)n * 32, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dy.p, y, (size_t)n * 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_diag_hash, dim3((n + 63) / 64), dim3(64), 0, h->stream, dx.p, dy.p, d33.p, d65.p, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h33, d33.p, (size_t)n * 20, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(h65, d65.p, (size_t)n * 20, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_diag_bloom(ecl_hip* h, const uint32_t (*h160)[5], uint8_t* hit, uint32_t n) {
+  if (!h || !h160 || !hit || n == 0) return ECL_E_ARG;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  HIPCHK(h, hipSetDevice(h->dev));
+  dbuf<u32> dh;
+  dbuf<u8> dhit;
+  HIPCHK(h, hipMalloc(&dh.p, (size_t)n * 20));
+  HIPCHK(h, hipMalloc(&dhit.p, n));
+  HIPCHK(h, hipMemcpy(dh.p, h160, (size_t)n * 20, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_diag_bloom, dim3((n + 63) / 64), dim3(64), 0, h->stream, bloom_make(h->d_bloom, h->bloom_words),
+                     dh.p, dhit.p, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}

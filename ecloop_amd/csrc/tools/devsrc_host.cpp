@@ -1,0 +1,49 @@
+// devsrc_host.cpp — compiles the DEVICE headers (fe256.h, hash160.h, ...) for the host with g++ so the CPU
+// test-suite can check the kernel source's logic against the oracle without a GPU
+// (tests/test_devsrc_host.py).  Not part of the product library.
+#include "../bloom.h"
+#include "../ec.h"
+#include "../hash160.h"
+#include <string.h>
+
+static fe ld(const uint64_t a[4]) {
+  fe r;
+  for (int i = 0; i < 4; ++i) r.v[2 * i] = (u32)a[i], r.v[2 * i + 1] = (u32)(a[i] >> 32);
+  return r;
+}
+static void st(uint64_t r[4], const fe& a) {
+  for (int i = 0; i < 4; ++i) r[i] = (uint64_t)a.v[2 * i] | (uint64_t)a.v[2 * i + 1] << 32;
+}
+extern "C" {
+void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  fe x = ld(a), y = ld(b), z;
+  switch (op) {
+  case 0: z = fe_mul(x, y); break;
+  case 1: z = fe_sqr(x); break;
+  case 2: z = fe_inv(x); break;
+  case 3: z = fe_sub(x, y); break;
+  case 4: z = fe_add(x, y); break;
+  case 5: z = fe_neg(x); break;
+  default: z = fe_zero();
+  }
+  st(r, z);
+}
+void dh_hash160(uint32_t h33[5], uint32_t h65[5], const uint64_t x[4], const uint64_t y[4]) {
+  fe fx = ld(x), fy = ld(y);
+  hash160_33(h33, fx, fy.v[0] & 1);
+  hash160_65(h65, fx, fy);
+}
+// k*G by the device's double-and-add, affine out; returns 0 if the result is the point at infinity
+int dh_mulg(uint64_t x[4], uint64_t y[4], const uint64_t k[4]) {
+  u32 kw[8];
+  for (int i = 0; i < 4; ++i) kw[2 * i] = (u32)k[i], kw[2 * i + 1] = (u32)(k[i] >> 32);
+  fe ax, ay;
+  int ok = ec_mul_g_affine(ax, ay, kw);
+  st(x, ax), st(y, ay);
+  return ok;
+}
+int dh_bloom_has(const uint64_t* bits, uint64_t nwords, const uint32_t h[5]) {
+  bloom_t b = bloom_make(bits, nwords);
+  return bloom_has(b, h) ? 1 : 0;
+}
+}

@@ -1,0 +1,166 @@
+// ubench.hip — instruction issue-rate microbenchmark for gfx950 (MI355X).
+// Calibrates the integer-VALU roofline that bench.py / DESIGN.md price the key-search kernel against:
+// the hot path is 32x32->64 multiply-add (v_mad_u64_u32), carry adds, and the rotate/xor/select mix of
+// SHA-256 / RIPEMD-160, none of which has a published rate for CDNA4.
+//   hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench && ./ubench
+// Output: one line per instruction: G wave-instr/s over the chip, and cycles per wave-instruction per SIMD
+// (using the device's reported clock), 8 independent dependency chains per lane, 8 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+#define ITERS 4096
+
+// ---- 32-bit in/out, two sources: d = op(d, a)
+#define K32_2(NAME, OPSTR)                                                                      \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a = seed ^ threadIdx.x;                                                      \
+    for (int i = 0; i < 8; ++i) r[i] = a * (i + 3);                                             \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                           \
+          asm volatile(OPSTR " %0, %0, %1" : "+v"(r[i]) : "v"(a));                              \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+// ---- 32-bit, three sources: d = op(d, a, b)
+#define K32_3(NAME, OPSTR)                                                                      \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a = seed ^ threadIdx.x, b = a * 7 + 1;                                       \
+    for (int i = 0; i < 8; ++i) r[i] = a * (i + 3);                                             \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                           \
+          asm volatile(OPSTR " %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));                  \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+
+K32_2(k_add_u32, "v_add_u32")
+K32_2(k_xor_b32, "v_xor_b32")
+K32_2(k_add_u32_e64, "v_add_u32_e64")
+K32_2(k_and_b32, "v_and_b32")
+K32_2(k_lshlrev_b32, "v_lshlrev_b32")
+K32_2(k_sub_u32, "v_sub_u32")
+K32_2(k_mul_lo_u32, "v_mul_lo_u32")
+K32_2(k_mul_hi_u32, "v_mul_hi_u32")
+K32_2(k_mul_u32_u24, "v_mul_u32_u24")
+K32_3(k_add3_u32, "v_add3_u32")
+K32_3(k_bfi_b32, "v_bfi_b32")
+K32_3(k_alignbit_b32, "v_alignbit_b32")
+K32_3(k_mad_u32_u24, "v_mad_u32_u24")
+K32_3(k_and_or_b32, "v_and_or_b32")
+K32_3(k_perm_b32, "v_perm_b32")
+K32_3(k_lshl_add_u32, "v_lshl_add_u32")
+K32_3(k_mad_i32_i24, "v_mad_i32_i24")
+
+// carry chain: v_add_co_u32 + v_addc_co_u32 pairs (VOP2, implicit vcc)
+__global__ void k_addc_pair(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], a = seed ^ threadIdx.x;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2)
+        asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(r[i]), "+v"(r[i + 1]) : "v"(a) : "vcc");
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+  if (s == 0x12345) out[0] = s;
+}
+
+// 64-bit destination ops
+#define K64(NAME, ASM_BODY)                                                                     \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint64_t r[8]; uint32_t a = seed ^ threadIdx.x, b = a * 7 + 1;                              \
+    for (int i = 0; i < 8; ++i) r[i] = (uint64_t)a * (i + 3);                                   \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { ASM_BODY; }                             \
+      }                                                                                         \
+    }                                                                                           \
+    uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = (uint32_t)s;                                                     \
+  }
+K64(k_mad_u64_u32, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc"))
+K64(k_mad_u64_u32_sgpr, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "s"(seed) : "vcc"))
+K64(k_mad_u64_u32_addc, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(r[i]), "+v"(b) : "v"(a), "v"(seed) : "vcc"))
+K64(k_lshl_add_u64, asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7])))
+K64(k_lshrrev_b64, asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(r[i])))
+K64(k_mul_f64, asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7])))
+K64(k_fma_f64, asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(r[i]) : "v"(r[(i + 1) & 7])))
+K64(k_add_f64, asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7])))
+K64(k_pk_fma_f32, asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(r[(i + 1) & 7])))
+K64(k_pk_add_u16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*(uint32_t*)&r[i]) : "v"(a)))
+K32_3(k_fma_f32, "v_fma_f32")
+
+// dependent chain latency: one accumulator
+__global__ void k_mad_u64_dep(uint32_t* out, uint32_t seed) {
+  uint64_t r = seed ^ threadIdx.x; uint32_t a = seed, b = a * 7 + 1;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r) : "v"(a), "v"(b) : "vcc");
+  }
+  if (r == 0x12345) out[0] = (uint32_t)r;
+}
+__global__ void k_add_dep(uint32_t* out, uint32_t seed) {
+  uint32_t r = seed ^ threadIdx.x, a = seed;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(a));
+  }
+  if (r == 0x12345) out[0] = r;
+}
+
+typedef void (*kern_t)(uint32_t*, uint32_t);
+struct Entry { const char* name; kern_t k; double per_iter; };
+
+int main(int argc, char** argv) {
+  int dev = 0; CHECK(hipSetDevice(dev));
+  hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, dev));
+  int cus = p.multiProcessorCount; double clk = p.clockRate * 1e3;  // Hz
+  printf("# device %s, %d CUs, clock %.0f MHz, wave %d\n", p.gcnArchName, cus, clk / 1e6, p.warpSize);
+  uint32_t* out; CHECK(hipMalloc(&out, 4096));
+  Entry es[] = {
+      {"v_add_u32 (e32)", k_add_u32, 32}, {"v_xor_b32 (e32)", k_xor_b32, 32}, {"v_and_b32 (e32)", k_and_b32, 32},
+      {"v_lshlrev_b32 (e32)", k_lshlrev_b32, 32}, {"v_sub_u32 (e32)", k_sub_u32, 32}, {"v_add_u32_e64", k_add_u32_e64, 32},
+      {"v_add3_u32", k_add3_u32, 32},
+      {"v_bfi_b32", k_bfi_b32, 32}, {"v_alignbit_b32", k_alignbit_b32, 32}, {"v_and_or_b32", k_and_or_b32, 32},
+      {"v_perm_b32", k_perm_b32, 32}, {"v_lshl_add_u32", k_lshl_add_u32, 32},
+      {"v_add_co+v_addc_co (per instr)", k_addc_pair, 32},
+      {"v_mul_lo_u32", k_mul_lo_u32, 32}, {"v_mul_hi_u32", k_mul_hi_u32, 32}, {"v_mul_u32_u24", k_mul_u32_u24, 32},
+      {"v_mad_u32_u24", k_mad_u32_u24, 32}, {"v_mad_i32_i24", k_mad_i32_i24, 32},
+      {"v_mad_u64_u32", k_mad_u64_u32, 32}, {"v_mad_u64_u32 (sgpr src)", k_mad_u64_u32_sgpr, 32},
+      {"v_mad_u64_u32+v_addc (per pair)", k_mad_u64_u32_addc, 32},
+      {"v_lshl_add_u64", k_lshl_add_u64, 32}, {"v_lshrrev_b64", k_lshrrev_b64, 32},
+      {"v_fma_f32", k_fma_f32, 32}, {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"v_pk_add_u16", k_pk_add_u16, 32},
+      {"v_add_f64", k_add_f64, 32}, {"v_mul_f64", k_mul_f64, 32}, {"v_fma_f64", k_fma_f64, 32},
+      {"v_mad_u64_u32 dependent chain", k_mad_u64_dep, 32}, {"v_add_u32 dependent chain", k_add_dep, 32},
+  };
+  int waves_per_simd = argc > 1 ? atoi(argv[1]) : 8;
+  int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  printf("%-36s %14s %16s\n", "instruction", "Gwave-instr/s", "cyc/instr/SIMD");
+  for (auto& e : es) {
+    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 12345u);  // warm
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, out, 12345u);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double instrs = 3.0 * blocks * 4.0 * ITERS * e.per_iter;  // wave-instructions
+    double rate = instrs / (ms * 1e-3);
+    double cyc = (cus * 4.0 * clk) / rate;  // SIMD-cycles per wave-instr
+    printf("%-36s %14.1f %16.2f\n", e.name, rate / 1e9, cyc);
+  }
+  return 0;
+}

@@ -1,0 +1,111 @@
+/*
+ * ecloop_hip.h — C ABI of the MI355X (gfx950) key-search engine: the drop-in boundary for ecloop's hot path.
+ *
+ * The reference (vladkens/ecloop v0.5.0) has no plugin/FFI seam: the hot path is reached by static calls inside
+ * one translation unit.  This header cuts the seam at the L4 -> L3 call:
+ *
+ *   reference call site                                   replaced by
+ *   ---------------------------------------------------   ------------------------------------------
+ *   batch_add(ctx, pk, iterations)          main.c:349    ecl_hip_add_range()
+ *     + check_found_add / check_hash        main.c:278-347  (device: hash160 + bloom probe; hits returned)
+ *   ctx_precompute_gpoints(ctx)             main.c:219    done inside ecl_hip_open()/first add_range
+ *   ec_gtable_mul xN + ec_jacobi_grprdc
+ *     + check_found_mul                     main.c:531-534  ecl_hip_mul_batch()
+ *   blf_has(&ctx->blf, h)                   utils.c:308   device probe of the bits given to ecl_hip_set_bloom()
+ *   ctx->check_addr33/65, use_endo, ord_offs main.c:32-34,67  flags / ord_offs of ecl_hip_open()
+ *
+ * What stays on the host, unchanged in meaning: filter loading (main.c:71-131), the sorted-list confirm after a
+ * bloom hit (main.c:212-216), calc_priv (main.c:267-276), pk_verify_hash (main.c:248-263), the found sink and
+ * status line (main.c:134-203), the job scheduler (main.c:405-454).  The device reports bloom hits as
+ * {key offset, endo index, address type, hash160}; the host turns them into private keys.
+ *
+ * Plain C types only: pointers, sizes, fixed-width integers.  No stdout/stderr/exit inside the library.
+ * One handle = one GPU; a handle must be used by one host thread at a time (one thread per device is the
+ * intended multi-GPU pattern: the keyspace is range-partitioned, there is no collective).
+ */
+#ifndef ECLOOP_HIP_H
+#define ECLOOP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ecl_hip ecl_hip; /* opaque per-device context */
+
+/* flags of ecl_hip_open: which encodings to hash (main.c:819-827) and the endomorphism switch (main.c:829) */
+#define ECL_ADDR33 1u
+#define ECL_ADDR65 2u
+#define ECL_ENDO 4u
+
+/* return codes */
+#define ECL_OK 0
+#define ECL_E_ARG (-1)      /* bad argument */
+#define ECL_E_HIP (-2)      /* HIP runtime error: ecl_hip_last_error() has the text */
+#define ECL_E_NODEV (-3)    /* no such device / no gfx950 code object for it */
+#define ECL_E_OVERFLOW (-4) /* more hits than `cap`: *nout = total hits, only `cap` records were written */
+#define ECL_E_NOBLOOM (-5)  /* add/mul called before ecl_hip_set_bloom */
+#define ECL_E_RANGE (-6)    /* range touches the scalar 0 (mod n) neighbourhood the method cannot represent */
+
+/* One bloom-filter hit.  key_offset counts keys from the `start` scalar of the call in units of the stride:
+   privkey = start + key_offset * 2^ord_offs (mod n), then the endo map of calc_priv (main.c:267-276):
+   endo 0: k, 1: -k, 2: k*lambda, 3: -k*lambda, 4: k*lambda^2, 5: -k*lambda^2.
+   For ecl_hip_mul_batch key_offset is the index into the scalar array and endo is 0.
+   h160 uses the reference's h160_t convention (addr.c:16): word i = digest bytes 4i..4i+3, big-endian. */
+typedef struct ecl_found {
+  uint64_t key_offset;
+  uint32_t h160[5];
+  uint8_t endo;
+  uint8_t compressed; /* 1 = addr33, 0 = addr65 */
+  uint8_t pad[2];
+} ecl_found; /* 32 bytes */
+
+int ecl_hip_device_count(void);
+
+/* Create a context on `device`. ord_offs: stride between consecutive keys is 2^ord_offs (0..255, main.c:221-222). */
+int ecl_hip_open(ecl_hip **out, int device, uint32_t flags, uint32_t ord_offs);
+void ecl_hip_close(ecl_hip *h);
+
+/* Copy the bloom bit array (little-endian u64 words, exactly the payload of a .blf file / of the in-memory
+   filter built from a hash list, utils.c:277-280) into HBM.  May be called again to replace the filter. */
+int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
+
+/* Hash the nkeys keys  start, start+s, ..., start+(nkeys-1)*s  (s = 2^ord_offs; every encoding / endo variant
+   selected at open) and report every bloom hit.  start: 256-bit scalar, 4 little-endian u64 limbs, as `fe`.
+   Exactly these keys are tested - the caller reproduces the reference's job rounding (main.c:442,368).
+   Consecutive calls whose `start` continues the previous range reuse the on-device walk state.
+   Returns ECL_OK, ECL_E_OVERFLOW (see above) or an error. */
+int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_found *out, uint32_t cap,
+                      uint32_t *nout);
+
+/* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index. */
+int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
+                      uint32_t *nout);
+
+/* Geometry of the walk: half_group = table points per group (the reference fixes 1024: GROUP_INV_SIZE/2,
+   main.c:17), max_lanes = keys walked concurrently.  0 keeps the default.  Results do not depend on either. */
+int ecl_hip_set_geometry(ecl_hip *h, uint32_t half_group, uint32_t max_lanes);
+
+/* Measurement: accumulated HIP-event time of the main add kernel since the last reset, and launch count. */
+int ecl_hip_get_timing(ecl_hip *h, double *kernel_ms, uint64_t *launches, uint64_t *keys);
+int ecl_hip_reset_timing(ecl_hip *h);
+
+const char *ecl_hip_strerror(int code);
+const char *ecl_hip_last_error(const ecl_hip *h);
+
+/* ---- diagnostics: device primitives exposed for parity tests (each runs a tiny kernel) ---- */
+/* op: 0 mul, 1 sqr, 2 inv, 3 sub, 4 add, 5 neg; a,b,r: n field elements as 4 little-endian u64 limbs */
+int ecl_hip_diag_fe(ecl_hip *h, int op, const uint64_t (*a)[4], const uint64_t (*b)[4], uint64_t (*r)[4], uint32_t n);
+/* affine public keys of n scalars (double-and-add kernel); ok[i] = 0 for the point at infinity */
+int ecl_hip_diag_mulg(ecl_hip *h, const uint64_t (*k)[4], uint64_t (*x)[4], uint64_t (*y)[4], uint8_t *ok, uint32_t n);
+/* hash160 of n affine points, both encodings */
+int ecl_hip_diag_hash160(ecl_hip *h, const uint64_t (*x)[4], const uint64_t (*y)[4], uint32_t (*h33)[5],
+                         uint32_t (*h65)[5], uint32_t n);
+/* bloom probe of n hashes against the resident filter */
+int ecl_hip_diag_bloom(ecl_hip *h, const uint32_t (*h160)[5], uint8_t *hit, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""GPU parity of the `add` hot path through the C ABI: per-key dumps via the all-ones bloom (every hashed key is a
+hit) against the reference's golden dumps and against the oracle, plus false-positive lists on synthetic blooms."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from synth import synth_bloom_words
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+G = json.load(open(os.path.join(GOLD, "golden.json")))["cases"]
+ONES = np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64)
+LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+
+
+def privkey(start, off, offs, endo):
+    """calc_priv (main.c:267-276) in python ints"""
+    k = (start + (off << offs)) % orc.N
+    if endo in (2, 3):
+        k = k * LAM % orc.N
+    if endo in (4, 5):
+        k = k * LAM % orc.N * LAM % orc.N
+    if endo in (1, 3, 5):
+        k = (-k) % orc.N
+    return k
+
+
+def lines_of(recs, start, offs=0):
+    return sorted("%s\t%s\t%064x" % ("addr33" if r["compressed"] else "addr65", orc.hex160(r["h160"]),
+                                      privkey(start, int(r["key_offset"]), offs, int(r["endo"]))) for r in recs)
+
+
+def dev_dump(start, nkeys, a33=True, a65=False, endo=False, offs=0, bloom=ONES, geometry=None, cap=None):
+    from ecloop_amd import Device
+    d = Device(0, a33=a33, a65=a65, endo=endo, ord_offs=offs)
+    try:
+        if geometry:
+            d.set_geometry(*geometry)
+        d.set_bloom(bloom)
+        cap = cap or nkeys * (2 if a33 and a65 else 1) * (6 if endo else 1)
+        recs, n = d.add_range(start, nkeys, cap=cap)
+        assert n == len(recs)
+        return recs
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("geometry", [None, (64, 256), (16, 1024), (1024, 256), (33, 512)])
+def test_dump33_matches_reference_golden(geometry):
+    recs = dev_dump(0x8000, 2048, geometry=geometry)
+    lines = lines_of(recs, 0x8000)
+    g = G["dump33_8000_87ff"]
+    assert len(lines) == 2048 and orc.digest(lines) == g["sha256_sorted"]
+    z = np.load(os.path.join(GOLD, g["npz"]))
+    got = {int(r["key_offset"]): list(r["h160"]) for r in recs}
+    for h, pk in zip(z["h160"], z["pk"]):
+        assert got[int(pk[0]) - 0x8000] == list(h)
+
+
+def test_dump65_and_cu_endo_match_reference_golden():
+    lines = lines_of(dev_dump(0x8000, 2048, a33=False, a65=True), 0x8000)
+    assert orc.digest(lines) == G["dump65_8000_87ff"]["sha256_sorted"]
+    g = G["dump_cu_endo_8000_87ff"]
+    lines = lines_of(dev_dump(0x8000, 2048, a33=True, a65=True, endo=True, geometry=(128, 256)), 0x8000)
+    assert len(lines) == g["count"] == 24576 and lines[:64] == g["head"] and orc.digest(lines) == g["sha256_sorted"]
+
+
+def test_strided_and_overrun_dumps():
+    a = (1 << 164) + 0x12345
+    lines = lines_of(dev_dump(a, 2048, offs=128), a, 128)
+    assert orc.digest(lines) == G["dump33_stride128"]["sha256_sorted"]
+    lines = lines_of(dev_dump(0x9000, 4096, geometry=(256, 256)), 0x9000)
+    assert orc.digest(lines) == G["dump33_overrun_9000_9801"]["sha256_sorted"]
+
+
+def test_ragged_sizes_against_oracle():
+    """nkeys that are not multiples of the group, tiny ranges, one key: exactly nkeys keys are tested"""
+    flt = orc.OrcFilter(bloom_words=ONES)
+    rc, out, n, _, hashed = orc.add_range(flt, 0x123456, 0x123456 + 2048 * 3, threads=4, cap=1 << 14)
+    ref = {int(l.split("\t")[2], 16): l for l in orc.found_lines(out, n)}
+    for nkeys, geo in [(1, (8, 256)), (2, (8, 256)), (15, (8, 256)), (16, (8, 256)), (17, (8, 256)), (1000, (8, 256)),
+                       (4097, (8, 256)), (6144, (64, 256)), (6143, (1024, 256)), (5000, (100, 512))]:
+        lines = lines_of(dev_dump(0x123456, nkeys, geometry=geo), 0x123456)
+        assert lines == sorted(ref[0x123456 + i] for i in range(nkeys)), (nkeys, geo)
+
+
+def test_centre_equals_jump_point_doubling_path():
+    """start chosen so that one lane's centre coincides with the jump point T*2B*G (tangent fallback)"""
+    B, T = 8, 256
+    start = (2 * (T - 3) - 1) * B  # centre of group m=3... start + B + m*2B == T*2B  -> m = 2
+    assert (start + B) % (2 * B) == 0
+    nkeys = 2 * B * T * 2  # two groups per lane so the jump is exercised
+    flt = orc.OrcFilter(bloom_words=ONES)
+    lines = lines_of(dev_dump(start, nkeys, geometry=(B, T)), start)
+    xs = {}
+    for l in lines[:: max(1, len(lines) // 300)] + lines[-64:]:
+        k = int(l.split("\t")[2], 16)
+        x, y = orc.point_of(k)
+        assert l.split("\t")[1] == orc.hex160(orc.hash160(x, y, True)), hex(k)
+    assert len(lines) == nkeys
+
+
+def test_sparse_bloom_false_positives_and_continuation():
+    """same false-positive list as the reference over two reference jobs (2^22 keys);
+    done as two contiguous calls so the second one continues from the walk state left in HBM."""
+    from ecloop_amd import Device
+    g = G["sparse_fp33_two_jobs"]
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    d = Device(0)
+    try:
+        d.set_geometry(256, 4096)
+        d.set_bloom(words)
+        r1, n1 = d.add_range(0x8000, 1 << 21, cap=4096)
+        r2, n2 = d.add_range(0x8000 + (1 << 21), 1 << 21, cap=4096)
+        ms, launches, keys = d.timing()
+        assert launches == 2 and keys == 1 << 22 and ms > 0
+    finally:
+        d.close()
+    lines = sorted(lines_of(r1, 0x8000) + lines_of(r2, 0x8000 + (1 << 21)))
+    assert len(lines) == g["count"] and orc.digest(lines) == g["sha256_sorted"]
+
+
+def test_dense_bloom_cu_endo_false_positives():
+    g = G["dense_fp_cu_endo"]
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    recs = dev_dump(0x8000, 2048, a33=True, a65=True, endo=True, bloom=words, cap=4096)
+    lines = lines_of(recs, 0x8000)
+    assert len(lines) == g["count"] and orc.digest(lines) == g["sha256_sorted"]
+
+
+def test_overflow_is_reported():
+    from ecloop_amd import Device
+    d = Device(0)
+    try:
+        d.set_geometry(64, 256)
+        d.set_bloom(ONES)
+        recs, n = d.add_range(0x8000, 4096, cap=100)
+        assert n == 4096 and len(recs) == 100
+    finally:
+        d.close()
+
+
+def test_mul_batch_dump_matches_reference_golden():
+    from ecloop_amd import Device
+    ks = [orc.sn_from_hex(l.strip()) for l in open(os.path.join(GOLD, "mul_scalars.txt"))]
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        recs, n = d.mul_batch(ks, cap=2048)
+    finally:
+        d.close()
+    lines = sorted("%s\t%s\t%064x" % ("addr33" if r["compressed"] else "addr65", orc.hex160(r["h160"]), ks[int(r["key_offset"])])
+                   for r in recs)
+    g = G["mul_dump_cu"]
+    assert n == g["count"] and orc.digest(lines) == g["sha256_sorted"]

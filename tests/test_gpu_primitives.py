@@ -1,0 +1,73 @@
+"""GPU parity of the device primitives (through the C ABI's diagnostic entry points) against the CPU oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import orc
+from synth import synth_bloom_words
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ecloop_amd import Device
+    d = Device(0, a33=True, a65=True)
+    yield d
+    d.close()
+
+
+def test_field_ops(dev):
+    rnd = random.Random(11)
+    P = orc.P
+    edge = [0, 1, 2, P - 1, P - 2, 0x1000003D1, 1 << 255, P - 0x1000003D1, (1 << 32) - 1, (1 << 224) - 1,
+            (1 << 256) - 1 - 0x1000003D1]
+    edge = [e % P for e in edge]
+    a = edge * len(edge) + [rnd.randrange(P) for _ in range(4000)]
+    b = [y for y in edge for _ in edge] + [rnd.randrange(P) for _ in range(4000)]
+    assert dev.diag_fe(0, a, b) == [x * y % P for x, y in zip(a, b)]
+    assert dev.diag_fe(1, a) == [x * x % P for x in a]
+    assert dev.diag_fe(3, a, b) == [(x - y) % P for x, y in zip(a, b)]
+    assert dev.diag_fe(4, a, b) == [(x + y) % P for x, y in zip(a, b)]
+    assert dev.diag_fe(5, a) == [(-x) % P for x in a]
+    nz = [x for x in a if x][:1500]
+    assert dev.diag_fe(2, nz) == [pow(x, P - 2, P) for x in nz]
+
+
+def test_scalar_mul_and_hash160(dev):
+    rnd = random.Random(12)
+    ks = [1, 2, 3, 0xDC2A04, orc.N - 1, (orc.N + 1) // 2, 1 << 255, 0, orc.N] + [rnd.randrange(1, orc.N) for _ in range(120)]
+    xs, ys, ok = dev.diag_mulg(ks)
+    for k, x, y, o in zip(ks, xs, ys, ok):
+        if k % orc.N == 0:
+            assert o == 0
+        else:
+            assert o == 1 and (x, y) == orc.point_of(k), hex(k)
+    good = [(x, y) for k, x, y in zip(ks, xs, ys) if k % orc.N]
+    h33, h65 = dev.diag_hash160([g[0] for g in good], [g[1] for g in good])
+    for (x, y), a, b in zip(good, h33, h65):
+        assert list(a) == orc.hash160(x, y, True)
+        assert list(b) == orc.hash160(x, y, False)
+    # public KATs for G
+    h33, h65 = dev.diag_hash160([xs[0]], [ys[0]])
+    assert orc.hex160(h33[0]) == "751e76e8199196d454941c45d1b3a323f1433bd6"
+    assert orc.hex160(h65[0]) == "91b24bf9f5288532960ac687abb035127b1d28a5"
+
+
+@pytest.mark.parametrize("nwords,mode", [(12345, "a|(b&c)"), (1, "ones"), (2, "a|b"), (4099, "a|b"), (1 << 20, "a|b")])
+def test_bloom_probe(dev, nwords, mode):
+    w = np.full(1, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(nwords, 5, mode)
+    dev.set_bloom(w)
+    rnd = np.random.RandomState(7)
+    hs = rnd.randint(0, 1 << 32, size=(50000, 5), dtype=np.uint64).astype(np.uint32)
+    # members: add 200 hashes to a copy on the CPU, all must hit
+    w2 = w.copy()
+    p2 = w2.ctypes.data_as(orc.C.POINTER(orc.C.c_uint64))
+    for h in hs[:200]:
+        orc.lib().orc_blf_add(p2, orc.C.c_uint64(len(w2)), orc.H160(*[int(v) for v in h]))
+    dev.set_bloom(w2)
+    hit = dev.diag_bloom(hs)
+    exp = np.array([orc.lib().orc_blf_has(p2, orc.C.c_uint64(len(w2)), orc.H160(*[int(v) for v in h])) for h in hs], dtype=np.uint8)
+    assert hit[:200].all()
+    assert (hit == exp).all()
