@@ -26,7 +26,7 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_add_range",
-    "ecl_hip_mul_batch", "ecl_hip_set_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
+    "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
 ]
 
@@ -53,6 +53,8 @@ def load():
     lib.ecl_hip_set_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_add_range.argtypes = [P, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_mul_batch.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ecl_hip_bloom_insert.argtypes = [P, C.c_void_p, C.c_uint64]
+    lib.ecl_hip_get_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_set_geometry.argtypes = [P, C.c_uint32, C.c_uint32]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_reset_timing.argtypes = [P]
@@ -111,6 +113,15 @@ class Device:
     def set_bloom(self, words):
         w = np.ascontiguousarray(words, dtype=np.uint64)
         self._chk(self.lib.ecl_hip_set_bloom(self.h, w.ctypes.data, len(w)))
+
+    def bloom_insert(self, hashes):
+        H = np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)
+        self._chk(self.lib.ecl_hip_bloom_insert(self.h, H.ctypes.data, len(H)))
+
+    def get_bloom(self, nwords):
+        w = np.zeros(nwords, dtype=np.uint64)
+        self._chk(self.lib.ecl_hip_get_bloom(self.h, w.ctypes.data, nwords))
+        return w
 
     def set_geometry(self, half_group=0, max_lanes=0):
         self._chk(self.lib.ecl_hip_set_geometry(self.h, half_group, max_lanes))

@@ -67,3 +67,20 @@ FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) {
   }
   return true;
 }
+
+#if defined(__HIPCC__)
+// lib/utils.c:290-306 (blf_add) for one hash: 20 atomic ORs
+__device__ __forceinline__ void bloom_add(const bloom_t& b, u64* bits, const u32 h[5]) {
+  u64 a[5];
+  a[0] = (u64)h[0] << 32 | h[1];
+  a[1] = (u64)h[2] << 32 | h[3];
+  a[2] = (u64)h[4] << 32 | h[0];
+  a[3] = (u64)h[1] << 32 | h[2];
+  a[4] = (u64)h[3] << 32 | h[4];
+#pragma unroll
+  for (int p = 0; p < 20; ++p) {
+    u64 idx = bloom_index(a, p);
+    atomicOr((unsigned long long*)&bits[bloom_mod(b, idx >> 6)], 1ull << (idx & 63));
+  }
+}
+#endif

@@ -97,6 +97,15 @@ __global__ void k_diag_bloom(bloom_t b, const u32* h160, u8* hit, u32 n) {
   hit[i] = bloom_has(b, h) ? 1 : 0;
 }
 
+__global__ void k_bloom_insert(bloom_t b, u64* bits, const u32* h160, u64 n) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 h[5];
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h[w] = h160[i * 5 + w];
+  bloom_add(b, bits, h);
+}
+
 // ------------------------------------------------------------------------------------------------ context
 
 struct ecl_hip {
@@ -489,6 +498,35 @@ extern "C" int ecl_hip_diag_hash160(ecl_hip* h, const uint64_t (*x)[4], const ui
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h33, d33.p, (size_t)n * 20, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(h65, d65.p, (size_t)n * 20, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_bloom_insert(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
+  if (!h || (!h160 && n)) return ECL_E_ARG;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  const u64 chunk = 1ull << 24;  // 320 MB of hashes per upload
+  dbuf<u32> dh;
+  HIPCHK(h, hipMalloc(&dh.p, (size_t)(n < chunk ? n : chunk) * 20));
+  for (u64 at = 0; at < n; at += chunk) {
+    u64 m = n - at < chunk ? n - at : chunk;
+    HIPCHK(h, hipMemcpy(dh.p, h160 + at, (size_t)m * 20, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bloom_insert, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream,
+                       bloom_make(h->d_bloom, h->bloom_words), h->d_bloom, dh.p, m);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_get_bloom(ecl_hip* h, uint64_t* bits, uint64_t nwords) {
+  if (!h || !bits) return ECL_E_ARG;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (nwords != h->bloom_words) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(bits, h->d_bloom, nwords * sizeof(u64), hipMemcpyDeviceToHost));
   return ECL_OK;
 }
 

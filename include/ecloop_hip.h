@@ -71,6 +71,11 @@ void ecl_hip_close(ecl_hip *h);
    filter built from a hash list, utils.c:277-280) into HBM.  May be called again to replace the filter. */
 int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 
+/* blf_add (utils.c:290-306) in bulk: set the 20 bits of each of n hash160 values (h160_t words) in the resident
+   filter; ecl_hip_get_bloom copies the bit array back (e.g. to write a .blf file, utils.c:328-360). */
+int ecl_hip_bloom_insert(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
+int ecl_hip_get_bloom(ecl_hip *h, uint64_t *bits, uint64_t nwords);
+
 /* Hash the nkeys keys  start, start+s, ..., start+(nkeys-1)*s  (s = 2^ord_offs; every encoding / endo variant
    selected at open) and report every bloom hit.  start: 256-bit scalar, 4 little-endian u64 limbs, as `fe`.
    Exactly these keys are tested - the caller reproduces the reference's job rounding (main.c:442,368).
