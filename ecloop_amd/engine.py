@@ -187,6 +187,26 @@ def shard(total, rank, world, align=GROUP_INV_SIZE):
     return lo, hi - lo
 
 
+def gather_found(lines, dist=None):
+    """found lists of all ranks -> every rank (the reference's single found sink, main.c:182-203); host objects only"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(lines)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, list(lines))
+    return [l for part in parts for l in part]
+
+
+def max_over_ranks(seconds, dist=None):
+    """wall time of the slowest rank (the job is done when the last shard is)"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 # ----------------------------------------------------------------------------------------------- command drivers
 
 

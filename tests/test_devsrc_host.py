@@ -1,0 +1,73 @@
+"""The DEVICE source (ecloop_amd/csrc/*.h) compiled for the host with g++ and checked against the oracle on the CPU:
+covers the kernels' arithmetic / hashing / probe logic without a GPU (the -m gpu tests cover the generated code)."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from synth import synth_bloom_words
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def D(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("devhost") / "libdevhost.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                    os.path.join(ROOT, "ecloop_amd", "csrc", "tools", "devsrc_host.cpp")], check=True)
+    return C.CDLL(so)
+
+
+def test_field(D):
+    rnd = random.Random(3)
+    P = orc.P
+
+    def op(o, a, b=0):
+        r = orc.FE()
+        D.dh_fe_op(o, r, orc.fe(a), orc.fe(b))
+        return orc.val(r)
+
+    edge = [0, 1, 2, P - 1, P - 2, 0x1000003D1, 1 << 255, P - 0x1000003D1, (1 << 32) - 1, (1 << 224) - 1]
+    vals = edge + [rnd.randrange(P) for _ in range(200)]
+    for a in vals:
+        for b in vals[:24]:
+            assert op(0, a, b) == a * b % P
+            assert op(3, a, b) == (a - b) % P
+            assert op(4, a, b) == (a + b) % P
+        assert op(1, a) == a * a % P
+        assert op(5, a) == (-a) % P
+    for a in vals[1:40]:
+        assert op(2, a) == pow(a, P - 2, P)
+
+
+def test_scalar_mul_and_hash160(D):
+    rnd = random.Random(4)
+    for k in [1, 2, 3, 5, 0xDC2A04, orc.N - 1, (orc.N + 1) // 2, 1 << 255] + [rnd.randrange(1, orc.N) for _ in range(12)]:
+        x, y = orc.FE(), orc.FE()
+        assert D.dh_mulg(x, y, orc.fe(k)) == 1
+        assert (orc.val(x), orc.val(y)) == orc.point_of(k)
+        h33, h65 = orc.H160(), orc.H160()
+        D.dh_hash160(h33, h65, x, y)
+        assert list(h33) == orc.hash160(orc.val(x), orc.val(y), True)
+        assert list(h65) == orc.hash160(orc.val(x), orc.val(y), False)
+    x, y = orc.FE(), orc.FE()
+    assert D.dh_mulg(x, y, orc.fe(0)) == 0 and D.dh_mulg(x, y, orc.fe(orc.N)) == 0
+
+
+@pytest.mark.parametrize("nw,mode", [(12345, "a|(b&c)"), (1, "ones"), (2, "a|b"), (4099, "a|b"), (1 << 16, "a|b")])
+def test_bloom_probe(D, nw, mode):
+    w = np.full(1, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(nw, 5, mode)
+    pw = w.ctypes.data_as(C.POINTER(C.c_uint64))
+    rnd = random.Random(8)
+    hits = 0
+    for _ in range(5000):
+        h = orc.H160(*[rnd.getrandbits(32) for _ in range(5)])
+        a, b = D.dh_bloom_has(pw, C.c_uint64(nw), h), orc.lib().orc_blf_has(pw, C.c_uint64(nw), h)
+        assert a == b
+        hits += a
+    if mode == "ones":
+        assert hits == 5000

@@ -1,0 +1,124 @@
+"""CPU tests of the host side: the C ABI library loads and exports every declared symbol, the engine's filter /
+job / scalar logic agrees with the oracle and with the reference's golden status counters."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+from synth import write_blf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+G = json.load(open(os.path.join(GOLD, "golden.json")))["cases"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    from ecloop_amd.build import build_library
+    return build_library()
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol(built):
+    from ecloop_amd import capi
+    lib = capi.load()
+    header = open(os.path.join(ROOT, "include", "ecloop_hip.h")).read()
+    declared = set(re.findall(r"\b(ecl_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ecl_hip_strerror(-4).decode().startswith("more hits")
+    assert capi.C.sizeof(capi.Found) == 32
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ecloop_amd import Device, EclError
+    with pytest.raises(EclError):
+        Device(0)
+
+
+def test_job_plan_matches_reference_status_counters():
+    from ecloop_amd.engine import job_plan
+    for name, rs, re_, stride, hashed in [
+        ("cfg1_list_800000_ffffff", 0x800000, 0xFFFFFF, 1, 8388608),
+        ("make_add_8000_ffffff", 0x8000, 0xFFFFFF, 1, 16777216),
+        ("ci_smoke_8000_ffff", 0x8000, 0xFFFF, 1, 32768),
+        ("dump33_8000_87ff", 0x8000, 0x87FF, 1, 2048),
+        ("dump33_overrun_9000_9801", 0x9000, 0x9801, 1, 4096),
+        ("sparse_fp33_two_jobs", 0x8000, 0x208800, 1, 1 << 22),
+        ("dump33_stride128", (1 << 164) + 0x12345, (1 << 164) + 0x12346, 1 << 128, 2048),
+    ]:
+        job, njobs, h = job_plan(rs, re_, stride)
+        assert njobs * job == G[name]["status_checked"], name
+        assert h == hashed, name
+    job, njobs, h = job_plan(0x8000, 0xFFFFF)
+    assert njobs * job * 6 == G["endo_cu_list_8000_fffff"]["status_checked"]
+
+
+def test_shards_tile_the_scan_exactly():
+    from ecloop_amd.engine import shard
+    for total in (2048, 4096, 1 << 22, (1 << 22) + 2048, 1 << 32, 3 * 2048):
+        for world in (1, 2, 3, 4, 8):
+            at = 0
+            for r in range(world):
+                lo, cnt = shard(total, r, world)
+                assert lo == at and lo % 2048 == 0
+                at += cnt
+            assert at == total
+
+
+def test_calc_priv_and_hex_parsing_match_oracle():
+    from ecloop_amd.engine import calc_priv, scalar_from_hex
+    import random
+    rnd = random.Random(2)
+    for _ in range(50):
+        start, off, offs, endo = rnd.randrange(1, orc.N), rnd.randrange(1 << 40), rnd.choice([0, 1, 64, 128, 200]), rnd.randrange(6)
+        pk = orc.FE()
+        orc.lib().orc_calc_priv(pk, orc.fe(start), orc.fe(1 << offs), off, endo)
+        assert calc_priv(start, 1 << offs, off, endo) == orc.val(pk) % orc.N
+    for s in ("dc2a04", "0x00ff zz 01", "%x" % (orc.N + 7), "", "F" * 70):
+        assert scalar_from_hex(s) == orc.sn_from_hex(s)
+
+
+def test_load_filter_list_and_blf(tmp_path):
+    from ecloop_amd.engine import blf_load, blf_save, blf_size_words, load_filter, parse_hash_list
+    f = load_filter(os.path.join(GOLD, "btc-puzzles-hash"))
+    o = orc.OrcFilter(hashes=[h for h in orc.parse_hash_list(os.path.join(GOLD, "btc-puzzles-hash")) if h])
+    assert f.count == 160 and (f.words == o.bloom_words()).all()
+    assert f.confirm(f.hashes[3]) and not f.confirm([1, 2, 3, 4, 5])
+    assert len(parse_hash_list(os.path.join(GOLD, "btc-bw-hash"))) == 1080  # comment chunk dropped (see docstring)
+    assert blf_size_words(32768) == G["blf_gen_puzzles_32768"]["size_words"] == orc.lib().orc_blf_gen_size(32768)
+    p = str(tmp_path / "x.blf")
+    blf_save(p, f.words)
+    assert (blf_load(p) == f.words).all()
+    g = load_filter(p)
+    assert g.hashes is None and g.confirm([1, 2, 3, 4, 5])
+    with pytest.raises(ValueError):
+        open(str(tmp_path / "bad.blf"), "wb").write(b"\0" * 16)
+        load_filter(str(tmp_path / "bad.blf"))
+
+
+def test_blf_gen_bytes_on_host(tmp_path):
+    """host-side blf_add reproduces the reference's blf-gen file byte for byte"""
+    import hashlib
+    import struct
+    from ecloop_amd.engine import blf_add_host, blf_size_words, parse_hash_list
+    g = G["blf_gen_puzzles_32768"]
+    words = np.zeros(blf_size_words(32768), dtype=np.uint64)
+    blf_add_host(words, np.array(parse_hash_list(os.path.join(GOLD, "btc-puzzles-hash")), dtype=np.uint32))
+    raw = struct.pack("<IIQ", 0x45434246, 1, len(words)) + words.tobytes()
+    assert hashlib.sha256(raw).hexdigest() == g["sha256"]
+
+
+def test_parse_range_errors():
+    from ecloop_amd.engine import P, parse_range
+    assert parse_range(None) == (2048, P)
+    assert parse_range("8000:ffff") == (0x8000, 0xFFFF)
+    for bad in ("800:ffff", "8000", "ffff:8000"):  # (an end above p cannot occur: -r values are reduced mod n first)
+        with pytest.raises(ValueError):
+            parse_range(bad)
