@@ -32,8 +32,9 @@ struct ecl_found_dev {
 struct add_args {
   const u32* __restrict__ tab;  // [B][16]: x[8], y[8] of (i+1)*stride*G, canonical affine
   u32 jump[16];                 // x[8], y[8] of (T*2B*stride)*G
-  uint4* __restrict__ cxy;      // lane centres, planes {x.lo, x.hi, y.lo, y.hi} x T
-  uint4* __restrict__ scratch;  // prefix products, [(k*2 + half) * T + lane]
+  uint4* __restrict__ cxy;      // lane centres as canonical words, planes {x.lo, x.hi, y.lo, y.hi} x T
+  uint4* __restrict__ scratch;  // prefix products (10x26 limbs 0..7), [(k*2 + half) * T + lane]
+  uint2* __restrict__ scratch2; // prefix products (limbs 8..9), [k * T + lane]
   bloom_t bloom;
   ecl_found_dev* found;
   u32* counter;
@@ -44,28 +45,40 @@ struct add_args {
   u64 nkeys;  // keys with offset >= nkeys are not tested
 };
 
-FE_FN fe fe_ld2(const uint4* p, size_t stride) {
+// canonical words in two uint4 planes <-> fe
+FE_FN fe fe_ld_words2(const uint4* p, size_t stride) {
   uint4 lo = p[0], hi = p[stride];
+  const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return fe_from_words(w);
+}
+FE_FN void fe_st_words2(uint4* p, size_t stride, fe a) {  // normalises
+  fe_normalize(a);
+  u32 w[8];
+  fe_to_words(w, a);
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[stride] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// raw limbs (any magnitude) in planes uint4, uint4, uint2
+FE_FN fe fe_ld_limbs(const uint4* p4, size_t stride4, const uint2* p2) {
+  uint4 a = p4[0], b = p4[stride4];
+  uint2 c = p2[0];
   fe r;
-  r.v[0] = lo.x, r.v[1] = lo.y, r.v[2] = lo.z, r.v[3] = lo.w;
-  r.v[4] = hi.x, r.v[5] = hi.y, r.v[6] = hi.z, r.v[7] = hi.w;
+  r.n[0] = a.x, r.n[1] = a.y, r.n[2] = a.z, r.n[3] = a.w;
+  r.n[4] = b.x, r.n[5] = b.y, r.n[6] = b.z, r.n[7] = b.w;
+  r.n[8] = c.x, r.n[9] = c.y;
   return r;
 }
-FE_FN void fe_st2(uint4* p, size_t stride, const fe& a) {
-  p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-  p[stride] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+FE_FN void fe_st_limbs(uint4* p4, size_t stride4, uint2* p2, const fe& a) {
+  p4[0] = make_uint4(a.n[0], a.n[1], a.n[2], a.n[3]);
+  p4[stride4] = make_uint4(a.n[4], a.n[5], a.n[6], a.n[7]);
+  p2[0] = make_uint2(a.n[8], a.n[9]);
 }
+// 8 canonical words at p (wave-uniform table / argument data) -> fe
 FE_FN fe fe_ldw(const u32* p) {
-  fe r;
+  u32 w[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = p[i];
-  return r;
-}
-FE_FN fe fe_sel(bool c, const fe& a, const fe& b) {
-  fe r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = c ? a.v[i] : b.v[i];
-  return r;
+  for (int i = 0; i < 8; ++i) w[i] = p[i];
+  return fe_from_words(w);
 }
 
 __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32 h[5], u32 endo, u32 compressed) {
@@ -81,29 +94,48 @@ __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32
 }
 
 // hash every selected encoding / endomorphism image of the affine point (x, y) and probe the filter
-// (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327)
+// (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327).
+// x, y: magnitude <= 6.
 template <bool A33, bool A65, bool ENDO>
-__device__ __forceinline__ void check_point(const add_args& a, const fe& x, const fe& y, u64 off) {
-  fe bx, b2x, ny;
+__device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 off) {
+  u32 xw[3][8], yw[2][8], par = 0;
   if (ENDO) {
-    const fe beta = FE_BETA1;
-    bx = fe_mul(x, beta);
-    b2x = fe_neg(fe_add(x, bx));  // beta^2 = -1 - beta
+    const u32 bw[8] = FE_BETA1_W;
+    fe bx = fe_mul(x, fe_from_words(bw));  // magnitude 1
+    fe b2x = fe_neg(fe_add(x, bx), 7);     // beta^2 = -1 - beta
+    fe_normalize(bx);
+    fe_normalize(b2x);
+    fe_to_words(xw[1], bx);
+    fe_to_words(xw[2], b2x);
   }
-  if (ENDO && A65) ny = fe_neg(y);
+  fe_normalize(x);
+  fe_to_words(xw[0], x);
+  if (A65) {
+    fe_normalize(y);
+    fe_to_words(yw[0], y);
+    par = y.n[0] & 1u;
+    if (ENDO) {
+      fe ny = fe_neg(y, 1);  // y != 0 on the curve, so this is p - y after normalisation
+      fe_normalize(ny);
+      fe_to_words(yw[1], ny);
+    }
+  } else {
+    par = fe_parity(y);
+  }
   const int nvar = ENDO ? 6 : 1;
 #pragma unroll 1
   for (int e = 0; e < nvar; ++e) {
-    fe xs = x;
-    if (ENDO) xs = e < 2 ? x : (e < 4 ? bx : b2x);
-    u32 h[5];
+    u32 xs[8], h[5];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xs[i] = ENDO ? (e < 2 ? xw[0][i] : (e < 4 ? xw[1][i] : xw[2][i])) : xw[0][i];
     if (A33) {
-      hash160_33(h, xs, (y.v[0] ^ (u32)e) & 1u);  // parity(-y) = !parity(y): p is odd, y != 0
+      hash160_33(h, xs, (par ^ (u32)e) & 1u);  // parity(-y) = !parity(y): p is odd, y != 0
       if (bloom_has(a.bloom, h)) found_push(a, off, h, e, 1);
     }
     if (A65) {
-      fe ys = y;
-      if (ENDO) ys = (e & 1) ? ny : y;
+      u32 ys[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ys[i] = (ENDO && (e & 1)) ? yw[1][i] : yw[0][i];
       hash160_65(h, xs, ys);
       if (bloom_has(a.bloom, h)) found_push(a, off, h, e, 0);
     }
@@ -116,39 +148,42 @@ __global__ void __launch_bounds__(256) k_add(const add_args a) {
   const u32 T = a.T, B = a.B;
   if (g >= T) return;
   const size_t plane = T;
-  fe X = fe_ld2(a.cxy + g, plane), Y = fe_ld2(a.cxy + 2 * (size_t)T + g, plane);
+  // centre (X, Y): canonical in HBM, magnitude 1 in registers
+  fe X = fe_ld_words2(a.cxy + g, plane), Y = fe_ld_words2(a.cxy + 2 * (size_t)T + g, plane);
   const fe Jx = fe_ldw(a.jump), Jy = fe_ldw(a.jump + 8);
-  uint4* scr = a.scratch + g;
-  const size_t sstep = 2 * (size_t)T;  // one chain element = two planes
+  uint4* scr4 = a.scratch + g;
+  uint2* scr2 = a.scratch2 + g;
+  const size_t s4 = 2 * (size_t)T;  // one chain element = two uint4 planes + one uint2 plane
 
 #pragma unroll 1
   for (u32 b = 0; b < a.nb; ++b) {
     const u64 base = ((u64)b * T + g) * (2ull * B);
     if (base >= a.nkeys) break;  // groups only grow: nothing left for this lane
 
-    // ---- phase 1: prefix products of e_0 = Jx - X, e_k = Gx_{k-1} - X
+    // ---- phase 1: prefix products of e_0 = Jx - X, e_k = Gx_{k-1} - X   (differences have magnitude 3)
     fe acc = fe_sub(Jx, X);
     const bool dbl = fe_is_zero(acc);  // C == J: next centre is 2C (C == -J would be the scalar 0: excluded)
     if (dbl) acc = fe_one();
 #pragma unroll 1
     for (u32 k = 1; k <= B; ++k) {
-      fe_st2(scr + (size_t)(k - 1) * sstep, plane, acc);
+      fe_st_limbs(scr4 + (size_t)(k - 1) * s4, plane, scr2 + (size_t)(k - 1) * plane, acc);
       fe dx = fe_sub(fe_ldw(a.tab + (size_t)(k - 1) * 16), X);
       acc = fe_mul(acc, dx);
     }
     // ---- phase 2: one inversion for the whole chain
     fe inv = fe_inv(acc);
     // ---- phase 3: walk the chain backwards, emit C +- G_i
-    fe pre = fe_ld2(scr + (size_t)(B - 1) * sstep, plane);
+    fe pre = fe_ld_limbs(scr4 + (size_t)(B - 1) * s4, plane, scr2 + (size_t)(B - 1) * plane);
 #pragma unroll 1
     for (u32 k = B; k >= 1; --k) {
       const u32 i = k - 1;
       fe nxt = pre;
-      if (k >= 2) nxt = fe_ld2(scr + (size_t)(k - 2) * sstep, plane);  // prefetch for the next iteration
+      if (k >= 2) nxt = fe_ld_limbs(scr4 + (size_t)(k - 2) * s4, plane, scr2 + (size_t)(k - 2) * plane);  // prefetch
       const fe gx = fe_ldw(a.tab + (size_t)i * 16), gy = fe_ldw(a.tab + (size_t)i * 16 + 8);
       const fe dx = fe_sub(gx, X);
       const fe invk = fe_mul(inv, pre);  // 1 / (Gx_i - X)
       inv = fe_mul(inv, dx);
+      const fe nxg = fe_neg(fe_add(X, gx), 2);  // -(X + Gx), magnitude 3
       const int nwhich = (k == 1) ? 3 : 2;
 #pragma unroll 1
       for (int which = 0; which < nwhich; ++which) {
@@ -157,10 +192,10 @@ __global__ void __launch_bounds__(256) k_add(const add_args a) {
         bool valid = true;
         if (which < 2) {
           // lambda = (+-Gy - Y) / (Gx - X); x3 = lambda^2 - X - Gx; y3 = lambda (X - x3) - Y   (main.c:379-386)
-          fe s = which == 0 ? fe_sub(gy, Y) : fe_neg(fe_add(gy, Y));
+          fe s = which == 0 ? fe_sub(gy, Y) : fe_neg(fe_add(gy, Y), 2);  // magnitude 3
           fe lam = fe_mul(s, invk);
-          px = fe_sub(fe_sub(fe_sqr(lam), X), gx);
-          py = fe_sub(fe_mul(lam, fe_sub(X, px)), Y);
+          px = fe_add(fe_sqr(lam), nxg);                                   // magnitude 4
+          py = fe_sub(fe_mul(lam, fe_add(X, fe_neg(px, 4))), Y);           // X - px: magnitude 6; py: magnitude 3
           off = which == 0 ? base + B + 1 + i : base + (B - 1 - i);
           valid = which == 1 || i + 1 < B;
         } else {
@@ -178,10 +213,12 @@ __global__ void __launch_bounds__(256) k_add(const add_args a) {
       fe x2 = fe_sqr(X);
       lam = fe_mul(fe_add(fe_add(x2, x2), x2), fe_inv(fe_add(Y, Y)));
     }
-    fe Xn = fe_sub(fe_sub(fe_sqr(lam), X), Jx);
-    Y = fe_sub(fe_mul(lam, fe_sub(X, Xn)), Y);
-    X = Xn;
+    fe Xn = fe_add(fe_sqr(lam), fe_neg(fe_add(X, Jx), 2));           // magnitude 4
+    fe Yn = fe_sub(fe_mul(lam, fe_add(X, fe_neg(Xn, 4))), Y);        // magnitude 3
+    fe_normalize_weak(Xn);
+    fe_normalize_weak(Yn);
+    X = Xn, Y = Yn;
   }
-  fe_st2(a.cxy + g, plane, X);
-  fe_st2(a.cxy + 2 * (size_t)T + g, plane, Y);
+  fe_st_words2(a.cxy + g, plane, X);
+  fe_st_words2(a.cxy + 2 * (size_t)T + g, plane, Y);
 }

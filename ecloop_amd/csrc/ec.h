@@ -14,20 +14,31 @@ struct jac {
   u32 inf;  // 1 = point at infinity
 };
 
-FE_FN fe fe_dbl(const fe& a) { return fe_add(a, a); }
+// set-up code keeps every value at magnitude 1: add / subtract, then one weak normalisation
+FE_FN fe fe_addn(const fe& a, const fe& b) {
+  fe r = fe_add(a, b);
+  fe_normalize_weak(r);
+  return r;
+}
+FE_FN fe fe_subn(const fe& a, const fe& b) {
+  fe r = fe_sub(a, b);
+  fe_normalize_weak(r);
+  return r;
+}
+FE_FN fe fe_dbl(const fe& a) { return fe_addn(a, a); }
 
 // 2P, a = 0 curve: 2M + 5S ("dbl-2009-l")
 FE_FN jac jac_dbl(const jac& p) {
   jac r;
   r.inf = p.inf;
   fe A = fe_sqr(p.X), B = fe_sqr(p.Y), C = fe_sqr(B);
-  fe t = fe_sqr(fe_add(p.X, B));
-  fe D = fe_dbl(fe_sub(fe_sub(t, A), C));
-  fe E = fe_add(fe_dbl(A), A);
+  fe t = fe_sqr(fe_addn(p.X, B));
+  fe D = fe_dbl(fe_subn(fe_subn(t, A), C));
+  fe E = fe_addn(fe_dbl(A), A);
   fe F = fe_sqr(E);
-  r.X = fe_sub(F, fe_dbl(D));
+  r.X = fe_subn(F, fe_dbl(D));
   fe C8 = fe_dbl(fe_dbl(fe_dbl(C)));
-  r.Y = fe_sub(fe_mul(E, fe_sub(D, r.X)), C8);
+  r.Y = fe_subn(fe_mul(E, fe_subn(D, r.X)), C8);
   r.Z = fe_dbl(fe_mul(p.Y, p.Z));
   return r;
 }
@@ -42,8 +53,8 @@ FE_FN jac jac_madd(const jac& p, const fe& qx, const fe& qy) {
   fe zz = fe_sqr(p.Z);
   fe u2 = fe_mul(qx, zz);
   fe s2 = fe_mul(qy, fe_mul(zz, p.Z));
-  fe h = fe_sub(u2, p.X);
-  fe rr = fe_sub(s2, p.Y);
+  fe h = fe_subn(u2, p.X);
+  fe rr = fe_subn(s2, p.Y);
   if (fe_is_zero(h)) {
     if (fe_is_zero(rr)) return jac_dbl(p);
     jac r = p;
@@ -53,13 +64,13 @@ FE_FN jac jac_madd(const jac& p, const fe& qx, const fe& qy) {
   fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(p.X, hh);
   jac r;
   r.inf = 0;
-  r.X = fe_sub(fe_sub(fe_sqr(rr), hhh), fe_dbl(v));
-  r.Y = fe_sub(fe_mul(rr, fe_sub(v, r.X)), fe_mul(p.Y, hhh));
+  r.X = fe_subn(fe_subn(fe_sqr(rr), hhh), fe_dbl(v));
+  r.Y = fe_subn(fe_mul(rr, fe_subn(v, r.X)), fe_mul(p.Y, hhh));
   r.Z = fe_mul(p.Z, h);
   return r;
 }
 
-// Jacobian -> affine (x = X/Z^2, y = Y/Z^3); returns 0 for the point at infinity
+// Jacobian -> canonical affine (x = X/Z^2, y = Y/Z^3); returns 0 for the point at infinity
 FE_FN int jac_to_affine(fe& x, fe& y, const jac& p) {
   if (p.inf) {
     x = fe_zero(), y = fe_zero();
@@ -68,12 +79,15 @@ FE_FN int jac_to_affine(fe& x, fe& y, const jac& p) {
   fe zi = fe_inv(p.Z), zi2 = fe_sqr(zi);
   x = fe_mul(p.X, zi2);
   y = fe_mul(p.Y, fe_mul(zi2, zi));
+  fe_normalize(x);
+  fe_normalize(y);
   return 1;
 }
 
 // k*G, MSB-first double-and-add (the reference's ec_jacobi_mulrdc(&G1, k), lib/ecc.c:821-853, by value)
 __host__ __device__ __noinline__ inline int ec_mul_g_affine(fe& x, fe& y, const u32 k[8]) {
-  const fe gx = FE_GX, gy = FE_GY;
+  const u32 gxw[8] = FE_GX_W, gyw[8] = FE_GY_W;
+  const fe gx = fe_from_words(gxw), gy = fe_from_words(gyw);
   jac acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
 #pragma unroll 1

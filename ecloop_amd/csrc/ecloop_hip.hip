@@ -24,8 +24,10 @@ __global__ void __launch_bounds__(64) k_mul_g(const u32* __restrict__ k, u32* __
   for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
   fe x, y;
   int fin = ec_mul_g_affine(x, y, kk);
+  u32 xw[8], yw[8];
+  fe_to_words(xw, x), fe_to_words(yw, y);
 #pragma unroll
-  for (int w = 0; w < 8; ++w) out[(size_t)i * 16 + w] = x.v[w], out[(size_t)i * 16 + 8 + w] = y.v[w];
+  for (int w = 0; w < 8; ++w) out[(size_t)i * 16 + w] = xw[w], out[(size_t)i * 16 + 8 + w] = yw[w];
   if (ok) ok[i] = (u8)fin;
 }
 
@@ -43,8 +45,8 @@ __global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0
   }
   fe x, y;
   jac_to_affine(x, y, acc);
-  fe_st2(cxy + g, T, x);
-  fe_st2(cxy + 2 * (size_t)T + g, T, y);
+  fe_st_words2(cxy + g, T, x);
+  fe_st_words2(cxy + 2 * (size_t)T + g, T, y);
 }
 
 // `mul` command body: public key of each scalar, hash, probe (main.c:530-534, 458-479)
@@ -71,17 +73,22 @@ __global__ void k_diag_fe(int op, const u32* a, const u32* b, u32* r, u32 n) {
   case 2: z = fe_inv(x); break;
   case 3: z = fe_sub(x, y); break;
   case 4: z = fe_add(x, y); break;
-  default: z = fe_neg(x); break;
+  default: z = fe_neg(x, 1); break;
   }
+  fe_normalize(z);
+  u32 zw[8];
+  fe_to_words(zw, z);
 #pragma unroll
-  for (int w = 0; w < 8; ++w) r[(size_t)i * 8 + w] = z.v[w];
+  for (int w = 0; w < 8; ++w) r[(size_t)i * 8 + w] = zw[w];
 }
 __global__ void k_diag_hash(const u32* x, const u32* y, u32* h33, u32* h65, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe fx = fe_ldw(x + (size_t)i * 8), fy = fe_ldw(y + (size_t)i * 8);
+  u32 fx[8], fy[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) fx[w] = x[(size_t)i * 8 + w], fy[w] = y[(size_t)i * 8 + w];
   u32 h[5];
-  hash160_33(h, fx, fy.v[0] & 1u);
+  hash160_33(h, fx, fy[0] & 1u);
 #pragma unroll
   for (int w = 0; w < 5; ++w) h33[(size_t)i * 5 + w] = h[w];
   hash160_65(h, fx, fy);
@@ -121,7 +128,7 @@ struct ecl_hip {
   u32* d_aux = nullptr;                        // [0]=C0, [1]=jump, [2..33]=ladder : 34 points x 16 words
   u32* d_auxk = nullptr;                       // scalars for the above
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
-  uint4* d_scr = nullptr; size_t scr_elems = 0;
+  uint4* d_scr = nullptr; uint2* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
@@ -192,7 +199,7 @@ void ecl_hip_close(ecl_hip* h) {
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
-  (void)hipFree(h->d_scr), (void)hipFree(h->d_bloom), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
+  (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -343,15 +350,17 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   size_t need = (size_t)T * B * 2;
   if (h->scr_elems < need) {
     if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
-    h->d_scr = nullptr, h->scr_elems = 0;
+    if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
+    h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
     HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
+    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(uint2)));
     h->scr_elems = need;
   }
 
   add_args a;
   a.tab = h->d_tab;
   memcpy(a.jump, h->jump_host, sizeof a.jump);
-  a.cxy = h->d_cxy, a.scratch = h->d_scr;
+  a.cxy = h->d_cxy, a.scratch = h->d_scr, a.scratch2 = h->d_scr2;
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
   a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
   a.B = B, a.T = T, a.nb = nb, a.nkeys = nkeys;

@@ -1,12 +1,20 @@
-// fe256.h — secp256k1 base-field arithmetic for gfx950 (device only).
+// fe256.h — secp256k1 base-field arithmetic for gfx950 (device; also compiles for the host for CPU-side tests).
 //
-// Replaces the reference's fe_modp_* family (lib/ecc.c:269-540) on the device.  Representation: 8 x u32
-// little-endian limbs held in VGPRs (one lane = one field element; the reference's 4 x u64 limbs are
-// the same bits).  p = 2^256 - K with K = 2^32 + 977, so a 512-bit product folds as lo + hi*977 + (hi<<32).
+// Replaces the reference's fe_modp_* family (lib/ecc.c:269-540) on the device.
 //
-// Contract (what makes the results bit-identical to the reference): every function returns the
-// CANONICAL residue in [0, p) for canonical inputs.  The reference hashes only canonical values
-// (DESIGN.md "Canonical form"), so any internally different-but-equivalent schedule gives the same bytes.
+// Representation: 10 limbs of 26 bits in u32 ("10x26", value = sum n[i] * 2^(26 i)), one lane = one element.
+// Why not the reference's 4 x u64 (or 8 x u32) saturated limbs: on gfx950 v_mad_u64_u32 (32x32+64 -> 64) issues
+// at the same rate as any other VOP3 instruction (profiles/ubench_r01.txt) but it has no carry-in, and a carry
+// chain costs an extra instruction plus wait states per link.  With 26-bit limbs a whole column of the schoolbook
+// product accumulates in one 64-bit register with no carry handling at all (10 products of < 2^60), additions and
+// subtractions are 10 independent 32-bit ops (no carry chain, no reduction), and the reduction by
+// 2^256 = 0x1000003D1 (mod p) is two small multiplies per column.
+//
+// Magnitude discipline (as in any unsaturated-limb field code): a value has magnitude m if n[i] <= 2m(2^26-1) for
+// i < 9 and n[9] <= 2m(2^22-1).  fe_mul / fe_sqr accept magnitudes <= 8 and return magnitude 1; fe_add adds
+// magnitudes; fe_neg(a, m) returns magnitude m+1.  Only fe_normalize() gives the canonical residue in [0, p), and
+// only canonical values are serialised for hashing, so results are bit-identical to the reference, which hashes
+// canonical values only (DESIGN.md "Canonical form").
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
@@ -25,214 +33,201 @@ typedef uint64_t u64;
 typedef uint8_t u8;
 
 struct fe {
-  u32 v[8];
+  u32 n[10];
 };
 
 #define FE_FN __host__ __device__ __forceinline__
+#define FE_M 0x3FFFFFFu
+#define FE_R0 0x3D10u /* 2^260 = R1 * 2^26 + R0 (mod p) */
+#define FE_R1 0x400u
 
-// p = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE FFFFFC2F
-#define FE_P0 0xFFFFFC2Fu
-#define FE_P1 0xFFFFFFFEu
-#define FE_K0 977u /* K = 2^32 + 977 */
+// p in 10x26 limbs
+#define FE_P0 0x3FFFC2Fu
+#define FE_P1 0x3FFFFBFu
+#define FE_PM 0x3FFFFFFu /* limbs 2..8 */
+#define FE_P9 0x03FFFFFu
 
 FE_FN fe fe_zero() {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  for (int i = 0; i < 10; ++i) r.n[i] = 0;
   return r;
 }
 FE_FN fe fe_one() {
   fe r = fe_zero();
-  r.v[0] = 1;
+  r.n[0] = 1;
   return r;
 }
-FE_FN bool fe_is_zero(const fe& a) {
+
+// 8 canonical little-endian u32 words (the reference's fe, lib/ecc.c:26) <-> limbs
+FE_FN fe fe_from_words(const u32 w[8]) {
+  fe r;
+  r.n[0] = w[0] & FE_M;
+  r.n[1] = (w[0] >> 26 | w[1] << 6) & FE_M;
+  r.n[2] = (w[1] >> 20 | w[2] << 12) & FE_M;
+  r.n[3] = (w[2] >> 14 | w[3] << 18) & FE_M;
+  r.n[4] = (w[3] >> 8 | w[4] << 24) & FE_M;
+  r.n[5] = (w[4] >> 2) & FE_M;
+  r.n[6] = (w[4] >> 28 | w[5] << 4) & FE_M;
+  r.n[7] = (w[5] >> 22 | w[6] << 10) & FE_M;
+  r.n[8] = (w[6] >> 16 | w[7] << 16) & FE_M;
+  r.n[9] = w[7] >> 10;
+  return r;
+}
+// a must be normalised
+FE_FN void fe_to_words(u32 w[8], const fe& a) {
+  w[0] = a.n[0] | a.n[1] << 26;
+  w[1] = a.n[1] >> 6 | a.n[2] << 20;
+  w[2] = a.n[2] >> 12 | a.n[3] << 14;
+  w[3] = a.n[3] >> 18 | a.n[4] << 8;
+  w[4] = a.n[4] >> 24 | a.n[5] << 2 | a.n[6] << 28;
+  w[5] = a.n[6] >> 4 | a.n[7] << 22;
+  w[6] = a.n[7] >> 10 | a.n[8] << 16;
+  w[7] = a.n[8] >> 16 | a.n[9] << 10;
+}
+
+// magnitude 1 result: the overflow above 2^256 folded in first, then one carry pass
+FE_FN void fe_normalize_weak(fe& a) {
+  u32 x = a.n[9] >> 22;
+  a.n[9] &= 0x03FFFFFu;
+  a.n[0] += x * 0x3D1u;
+  a.n[1] += x << 6;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    a.n[i + 1] += a.n[i] >> 26;
+    a.n[i] &= FE_M;
+  }
+}
+// 1 if a weakly normalised value (it is < 2p; n[9] may carry bit 22) is >= p
+FE_FN u32 fe_weak_ge_p(const fe& a) {
+  u32 m = a.n[2] & a.n[3] & a.n[4] & a.n[5] & a.n[6] & a.n[7] & a.n[8];
+  return (a.n[9] >> 22) |
+         ((a.n[9] == 0x03FFFFFu) & (m == FE_M) & ((a.n[1] + 0x40u + ((a.n[0] + 0x3D1u) >> 26)) > FE_M));
+}
+// canonical residue in [0, p)
+FE_FN void fe_normalize(fe& a) {
+  fe_normalize_weak(a);
+  u32 x = fe_weak_ge_p(a);
+  a.n[0] += x * 0x3D1u;
+  a.n[1] += x << 6;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    a.n[i + 1] += a.n[i] >> 26;
+    a.n[i] &= FE_M;
+  }
+  a.n[9] &= 0x03FFFFFu;  // drops 2^256 when x was set
+}
+// parity of the canonical residue without producing it (p is odd: subtracting it flips the parity)
+FE_FN u32 fe_parity(fe a) {
+  fe_normalize_weak(a);
+  return (a.n[0] ^ fe_weak_ge_p(a)) & 1u;
+}
+// is the value 0 mod p?  (any magnitude <= 8)
+FE_FN bool fe_is_zero(fe a) {
+  fe_normalize(a);
   u32 o = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i];
-  return o == 0;
-}
-FE_FN bool fe_eq(const fe& a, const fe& b) {
-  u32 o = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+  for (int i = 0; i < 10; ++i) o |= a.n[i];
   return o == 0;
 }
 
-// r = a + b over 2^256, returns carry (0/1)
-FE_FN u32 fe_add_raw(fe& r, const fe& a, const fe& b) {
-  u64 c = 0;
+FE_FN fe fe_add(const fe& a, const fe& b) {  // magnitude ma + mb
+  fe r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    c += (u64)a.v[i] + b.v[i];
-    r.v[i] = (u32)c;
-    c >>= 32;
-  }
-  return (u32)c;
+  for (int i = 0; i < 10; ++i) r.n[i] = a.n[i] + b.n[i];
+  return r;
 }
-// r = a - b over 2^256, returns borrow (0/1)
-FE_FN u32 fe_sub_raw(fe& r, const fe& a, const fe& b) {
-  u32 br = 0;
+// -a for a of magnitude <= m; result magnitude m + 1   (2(m+1)p - a, limb-wise, never underflows)
+FE_FN fe fe_neg(const fe& a, u32 m) {
+  fe r;
+  const u32 k = 2 * (m + 1);
+  r.n[0] = FE_P0 * k - a.n[0];
+  r.n[1] = FE_P1 * k - a.n[1];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u64 d = (u64)a.v[i] - b.v[i] - br;
-    r.v[i] = (u32)d;
-    br = (u32)(d >> 63);
-  }
-  return br;
+  for (int i = 2; i < 9; ++i) r.n[i] = FE_PM * k - a.n[i];
+  r.n[9] = FE_P9 * k - a.n[9];
+  return r;
 }
-// r += K*m (m = 0 or 1), i.e. subtract p modulo 2^256; returns carry
-FE_FN u32 fe_add_k(fe& r, u32 m) {
-  u64 c = (u64)r.v[0] + (FE_K0 & (0u - m));
-  r.v[0] = (u32)c;
-  c = (c >> 32) + r.v[1] + m;
-  r.v[1] = (u32)c;
-#pragma unroll
-  for (int i = 2; i < 8; ++i) {
-    c = (c >> 32) + r.v[i];
-    r.v[i] = (u32)c;
-  }
-  return (u32)(c >> 32);
-}
-// r -= K*m (m = 0 or 1), i.e. add p modulo 2^256
-FE_FN void fe_sub_k(fe& r, u32 m) {
-  u64 d = (u64)r.v[0] - (FE_K0 & (0u - m));
-  r.v[0] = (u32)d;
-  u32 br = (u32)(d >> 63);
-  d = (u64)r.v[1] - m - br;
-  r.v[1] = (u32)d;
-  br = (u32)(d >> 63);
-#pragma unroll
-  for (int i = 2; i < 8; ++i) {
-    d = (u64)r.v[i] - br;
-    r.v[i] = (u32)d;
-    br = (u32)(d >> 63);
-  }
-}
-// a >= p  (a < 2^256)
-FE_FN bool fe_ge_p(const fe& a) {
-  u32 hi = a.v[2] & a.v[3] & a.v[4] & a.v[5] & a.v[6] & a.v[7];
-  return hi == 0xFFFFFFFFu && (a.v[1] == 0xFFFFFFFFu || (a.v[1] == FE_P1 && a.v[0] >= FE_P0));
-}
-// canonicalise a value in [0, 2^256)
-FE_FN void fe_canon(fe& a) { fe_add_k(a, fe_ge_p(a) ? 1u : 0u); }
+// a - b for b of magnitude 1; result magnitude ma + 2
+FE_FN fe fe_sub(const fe& a, const fe& b) { return fe_add(a, fe_neg(b, 1)); }
 
-// a - b mod p, canonical for canonical inputs (lib/ecc.c:277-290)
-FE_FN fe fe_sub(const fe& a, const fe& b) {
-  fe r;
-  u32 br = fe_sub_raw(r, a, b);
-  fe_sub_k(r, br);
-  return r;
-}
-// a + b mod p, canonical for canonical inputs (the reference's add, lib/ecc.c:292-305, only reduces on
-// 2^256 overflow; the device version is used where the result must be canonical)
-FE_FN fe fe_add(const fe& a, const fe& b) {
-  fe r;
-  u32 c = fe_add_raw(r, a, b);
-  fe_add_k(r, c);  // wrapped: r + 2^256 == r + K (mod p); cannot carry again for canonical inputs
-  fe_canon(r);
-  return r;
-}
-// -a mod p for canonical nonzero a; neg(0) = 0 here (the reference returns p; never hashed)
-FE_FN fe fe_neg(const fe& a) {
-  fe z = fe_zero();
-  return fe_sub(z, a);
-}
-
-// 512-bit product, operand scanning: t[i+j] += a[j]*b[i]
-FE_FN void fe_mul_wide(u32 t[16], const fe& a, const fe& b) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u32 carry = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      u64 acc = (u64)a.v[j] * b.v[i] + t[i + j] + carry;
-      t[i + j] = (u32)acc;
-      carry = (u32)(acc >> 32);
-    }
-    t[i + 8] = carry;
-  }
-}
-// 512-bit square: off-diagonal products once, doubled, plus the diagonal
-FE_FN void fe_sqr_wide(u32 t[16], const fe& a) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    u32 carry = 0;
-#pragma unroll
-    for (int j = i + 1; j < 8; ++j) {
-      u64 acc = (u64)a.v[j] * a.v[i] + t[i + j] + carry;
-      t[i + j] = (u32)acc;
-      carry = (u32)(acc >> 32);
-    }
-    t[i + 8] = carry;
-  }
-  // double
-  u32 top = 0;
-#pragma unroll
-  for (int i = 1; i < 16; ++i) {
-    u32 nt = t[i] >> 31;
-    t[i] = (t[i] << 1) | top;
-    top = nt;
-  }
-  // add diagonal squares
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u64 sq = (u64)a.v[i] * a.v[i];
-    c += (u64)t[2 * i] + (u32)sq;
-    t[2 * i] = (u32)c;
-    c >>= 32;
-    c += (u64)t[2 * i + 1] + (u32)(sq >> 32);
-    t[2 * i + 1] = (u32)c;
-    c >>= 32;
-  }
-}
-// fold a 512-bit value to the canonical residue: lo + hi*977 + (hi << 32), then the 9th word once more
-FE_FN fe fe_reduce_wide(const u32 t[16]) {
-  fe r;
-  u64 acc = 0;
-  u32 prev = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    acc += (u64)t[8 + i] * FE_K0 + t[i] + prev;
-    r.v[i] = (u32)acc;
-    acc >>= 32;
-    prev = t[8 + i];
-  }
-  acc += prev;  // 9th word: < 2^34
-  // second fold: acc * K = acc*977 + (acc << 32)
-  u64 f0 = acc * FE_K0;  // < 2^44
-  u64 c = (u64)r.v[0] + (u32)f0;
-  r.v[0] = (u32)c;
-  c = (c >> 32) + r.v[1] + (f0 >> 32) + (u32)acc;
-  r.v[1] = (u32)c;
-  c = (c >> 32) + r.v[2] + (acc >> 32);
-  r.v[2] = (u32)c;
-#pragma unroll
-  for (int i = 3; i < 8; ++i) {
-    c = (c >> 32) + r.v[i];
-    r.v[i] = (u32)c;
-  }
-  // a carry out of 2^256 here means the true value is r + 2^256 == r + K (mod p); r is tiny then
-  fe_add_k(r, (u32)(c >> 32));
-  fe_canon(r);
-  return r;
-}
-// lib/ecc.c:307-347
+// lib/ecc.c:307-347. Inputs of magnitude <= 8, output magnitude 1.
+// Columns 9..18 stream through d (their 26-bit digits u are folded down by 2^260 = R1*2^26 + R0), columns 0..8
+// stream through c: every column is carried exactly once.
 FE_FN fe fe_mul(const fe& a, const fe& b) {
-  u32 t[16];
-  fe_mul_wide(t, a, b);
-  return fe_reduce_wide(t);
+  fe r;
+  u64 c = 0, d = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) d += (u64)a.n[i] * b.n[9 - i];
+  const u32 t9 = (u32)d & FE_M;
+  d >>= 26;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < 10; ++i) d += (u64)a.n[i] * b.n[10 + k - i];
+    const u32 u = (u32)d & FE_M;
+    d >>= 26;
+#pragma unroll
+    for (int i = 0; i <= k; ++i) c += (u64)a.n[i] * b.n[k - i];
+    c += (u64)u * FE_R0;
+    r.n[k] = (u32)c & FE_M;
+    c >>= 26;
+    c += (u64)u * FE_R1;
+  }
+  // column 9: what is left in d sits at 2^(26*19) = 2^(26*9) * 2^260
+  c += d * FE_R0 + t9;
+  r.n[9] = (u32)c & (FE_M >> 4);
+  c >>= 22;
+  c += d * ((u64)FE_R1 << 4);
+  // c * 2^256 = c * (2^32 + 977): limbs 0 and 1, then a short carry
+  d = c * (FE_R0 >> 4) + r.n[0];
+  r.n[0] = (u32)d & FE_M;
+  d >>= 26;
+  d += c * (FE_R1 >> 4) + r.n[1];
+  r.n[1] = (u32)d & FE_M;
+  d >>= 26;
+  r.n[2] += (u32)d;
+  return r;
 }
-// lib/ecc.c:349-444
+// lib/ecc.c:349-444. Same schedule with the symmetric products taken once against the doubled operand.
 FE_FN fe fe_sqr(const fe& a) {
-  u32 t[16];
-  fe_sqr_wide(t, a);
-  return fe_reduce_wide(t);
+  fe r;
+  u32 a2[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) a2[i] = a.n[i] * 2;
+  u64 c = 0, d = 0;
+  // column k = sum_{i<j, i+j=k} a_i * 2a_j  (+ a_{k/2}^2)
+#define FE_SQ_COL(acc, k)                                                  \
+  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); ++i)  \
+      acc += (u64)a.n[i] * a2[(k)-i];                                      \
+  if (((k)&1) == 0) acc += (u64)a.n[(k) / 2] * a.n[(k) / 2];
+  FE_SQ_COL(d, 9)
+  const u32 t9 = (u32)d & FE_M;
+  d >>= 26;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    FE_SQ_COL(d, 10 + k)
+    const u32 u = (u32)d & FE_M;
+    d >>= 26;
+    FE_SQ_COL(c, k)
+    c += (u64)u * FE_R0;
+    r.n[k] = (u32)c & FE_M;
+    c >>= 26;
+    c += (u64)u * FE_R1;
+  }
+#undef FE_SQ_COL
+  c += d * FE_R0 + t9;
+  r.n[9] = (u32)c & (FE_M >> 4);
+  c >>= 22;
+  c += d * ((u64)FE_R1 << 4);
+  d = c * (FE_R0 >> 4) + r.n[0];
+  r.n[0] = (u32)d & FE_M;
+  d >>= 26;
+  d += c * (FE_R1 >> 4) + r.n[1];
+  r.n[1] = (u32)d & FE_M;
+  d >>= 26;
+  r.n[2] += (u32)d;
+  return r;
 }
 
 __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {
@@ -240,7 +235,8 @@ __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {
   for (int i = 0; i < n; ++i) a = fe_sqr(a);
   return a;
 }
-// a^(p-2): the 255 S + 15 M addition chain of lib/ecc.c:463-520 (x2,x3,x6,x9,x11,x22,x44,x88,x176,x220,x223)
+// a^(p-2): the 255 S + 15 M addition chain of lib/ecc.c:463-520 (x2,x3,x6,x9,x11,x22,x44,x88,x176,x220,x223).
+// Input magnitude <= 8, output magnitude 1.
 __host__ __device__ __noinline__ inline fe fe_inv(const fe& a) {
   fe x2 = fe_mul(fe_sqr(a), a);
   fe x3 = fe_mul(fe_sqr(x2), a);
@@ -259,10 +255,10 @@ __host__ __device__ __noinline__ inline fe fe_inv(const fe& a) {
   return fe_mul(fe_sqr_n(t, 2), a);
 }
 
-// secp256k1 constants as limb initialisers (little-endian u32 words)
-#define FE_BETA1                                                                                                \
+// secp256k1 constants as canonical little-endian u32 words
+#define FE_BETA1_W                                                                                              \
   { 0x719501eeu, 0xc1396c28u, 0x12f58995u, 0x9cf04975u, 0xac3434e9u, 0x6e64479eu, 0x657c0710u, 0x7ae96a2bu }
-#define FE_GX                                                                                                   \
+#define FE_GX_W                                                                                                 \
   { 0x16f81798u, 0x59f2815bu, 0x2dce28d9u, 0x029bfcdbu, 0xce870b07u, 0x55a06295u, 0xf9dcbbacu, 0x79be667eu }
-#define FE_GY                                                                                                   \
+#define FE_GY_W                                                                                                 \
   { 0xfb10d4b8u, 0x9c47d08fu, 0xa6855419u, 0xfd17b448u, 0x0e1108a8u, 0x5da4fbfcu, 0x26a3c465u, 0x483ada77u }

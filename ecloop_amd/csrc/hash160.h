@@ -161,13 +161,14 @@ H_FN void rmd160_of_sha(u32 h[5], const u32 st[8]) {
 }
 
 // hash160 of the compressed key: prefix = 0x02 | parity(y)  (lib/addr.c:33-45, 99-114)
-H_FN void hash160_33(u32 h[5], const fe& x, u32 y_parity) {
+// x, y: 8 canonical little-endian u32 words each (fe_to_words of a normalised element)
+H_FN void hash160_33(u32 h[5], const u32 x[8], u32 y_parity) {
   u32 w[16], st[8];
   u32 prefix = 0x02u | (y_parity & 1u);
-  w[0] = (prefix << 24) | (x.v[7] >> 8);
+  w[0] = (prefix << 24) | (x[7] >> 8);
 #pragma unroll
-  for (int i = 1; i < 8; ++i) w[i] = (x.v[8 - i] << 24) | (x.v[7 - i] >> 8);
-  w[8] = (x.v[0] << 24) | 0x00800000u;
+  for (int i = 1; i < 8; ++i) w[i] = (x[8 - i] << 24) | (x[7 - i] >> 8);
+  w[8] = (x[0] << 24) | 0x00800000u;
 #pragma unroll
   for (int i = 9; i < 15; ++i) w[i] = 0;
   w[15] = 33 * 8;
@@ -176,17 +177,17 @@ H_FN void hash160_33(u32 h[5], const fe& x, u32 y_parity) {
   rmd160_of_sha(h, st);
 }
 // hash160 of the uncompressed key 04 || X || Y  (lib/addr.c:47-67, 116-131)
-H_FN void hash160_65(u32 h[5], const fe& x, const fe& y) {
+H_FN void hash160_65(u32 h[5], const u32 x[8], const u32 y[8]) {
   u32 w[16], st[8];
-  w[0] = (0x04u << 24) | (x.v[7] >> 8);
+  w[0] = (0x04u << 24) | (x[7] >> 8);
 #pragma unroll
-  for (int i = 1; i < 8; ++i) w[i] = (x.v[8 - i] << 24) | (x.v[7 - i] >> 8);
-  w[8] = (x.v[0] << 24) | (y.v[7] >> 8);
+  for (int i = 1; i < 8; ++i) w[i] = (x[8 - i] << 24) | (x[7 - i] >> 8);
+  w[8] = (x[0] << 24) | (y[7] >> 8);
 #pragma unroll
-  for (int i = 1; i < 8; ++i) w[8 + i] = (y.v[8 - i] << 24) | (y.v[7 - i] >> 8);
+  for (int i = 1; i < 8; ++i) w[8 + i] = (y[8 - i] << 24) | (y[7 - i] >> 8);
   sha256_init(st);
   sha256_compress(st, w);
-  w[0] = (y.v[0] << 24) | 0x00800000u;
+  w[0] = (y[0] << 24) | 0x00800000u;
 #pragma unroll
   for (int i = 1; i < 15; ++i) w[i] = 0;
   w[15] = 65 * 8;

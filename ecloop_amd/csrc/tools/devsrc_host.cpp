@@ -6,13 +6,19 @@
 #include "../hash160.h"
 #include <string.h>
 
-static fe ld(const uint64_t a[4]) {
-  fe r;
-  for (int i = 0; i < 4; ++i) r.v[2 * i] = (u32)a[i], r.v[2 * i + 1] = (u32)(a[i] >> 32);
-  return r;
+static void words(u32 w[8], const uint64_t a[4]) {
+  for (int i = 0; i < 4; ++i) w[2 * i] = (u32)a[i], w[2 * i + 1] = (u32)(a[i] >> 32);
 }
-static void st(uint64_t r[4], const fe& a) {
-  for (int i = 0; i < 4; ++i) r[i] = (uint64_t)a.v[2 * i] | (uint64_t)a.v[2 * i + 1] << 32;
+static fe ld(const uint64_t a[4]) {
+  u32 w[8];
+  words(w, a);
+  return fe_from_words(w);
+}
+static void st(uint64_t r[4], fe a) {
+  fe_normalize(a);
+  u32 w[8];
+  fe_to_words(w, a);
+  for (int i = 0; i < 4; ++i) r[i] = (uint64_t)w[2 * i] | (uint64_t)w[2 * i + 1] << 32;
 }
 extern "C" {
 void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
@@ -23,14 +29,17 @@ void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
   case 2: z = fe_inv(x); break;
   case 3: z = fe_sub(x, y); break;
   case 4: z = fe_add(x, y); break;
-  case 5: z = fe_neg(x); break;
+  case 5: z = fe_neg(x, 1); break;
+  case 6: z = fe_mul(fe_add(fe_add(x, x), fe_add(x, x)), fe_sub(fe_add(y, y), x)); break;  // magnitudes 4 and 4
+  case 7: z = fe_sqr(fe_add(fe_add(fe_add(x, x), fe_add(x, x)), fe_add(fe_add(y, y), fe_add(y, y)))); break;  // magnitude 8
   default: z = fe_zero();
   }
   st(r, z);
 }
 void dh_hash160(uint32_t h33[5], uint32_t h65[5], const uint64_t x[4], const uint64_t y[4]) {
-  fe fx = ld(x), fy = ld(y);
-  hash160_33(h33, fx, fy.v[0] & 1);
+  u32 fx[8], fy[8];
+  words(fx, x), words(fy, y);
+  hash160_33(h33, fx, fy[0] & 1);
   hash160_65(h65, fx, fy);
 }
 // k*G by the device's double-and-add, affine out; returns 0 if the result is the point at infinity
@@ -42,6 +51,7 @@ int dh_mulg(uint64_t x[4], uint64_t y[4], const uint64_t k[4]) {
   st(x, ax), st(y, ay);
   return ok;
 }
+int dh_parity(const uint64_t a[4], const uint64_t b[4]) { return (int)fe_parity(fe_sub(fe_add(ld(a), ld(a)), ld(b))); }
 int dh_bloom_has(const uint64_t* bits, uint64_t nwords, const uint32_t h[5]) {
   bloom_t b = bloom_make(bits, nwords);
   return bloom_has(b, h) ? 1 : 0;

@@ -103,6 +103,34 @@ K64(k_pk_fma_f32, asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(r[i]) : "v"(
 K64(k_pk_add_u16, asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(*(uint32_t*)&r[i]) : "v"(a)))
 K32_3(k_fma_f32, "v_fma_f32")
 
+// v_mad_u64_u32 with distinct multiplicand registers per chain and random data (as in a field multiplication)
+__global__ void k_mad_u64_distinct(uint32_t* out, uint32_t seed) {
+  uint64_t r[8]; uint32_t a[8], b[8];
+  for (int i = 0; i < 8; ++i) { a[i] = (seed ^ threadIdx.x) * 2654435761u * (i + 1) + 0x9E3779B9u; b[i] = a[i] * 40503u + 0x7F4A7C15u; r[i] = (uint64_t)a[i] * b[i]; }
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a[i]), "v"(b[(i + u) & 7]) : "vcc");
+    }
+  }
+  uint64_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+  if (s == 0x12345) out[0] = (uint32_t)s;
+}
+// column accumulation as the compiler emits it for 10x26: acc = a*b + acc with one accumulator per 5 products
+__global__ void k_mad_u64_column(uint32_t* out, uint32_t seed) {
+  uint64_t r[2] = {seed, seed * 3ull}; uint32_t a[10], b[10];
+  for (int i = 0; i < 10; ++i) { a[i] = ((seed ^ threadIdx.x) * 2654435761u * (i + 1)) & 0x3FFFFFF; b[i] = (a[i] * 40503u + 0x7F4A7C15u) & 0x3FFFFFF; }
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[0]) : "v"(a[u % 10]), "v"(b[(u * 3) % 10]) : "vcc");
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[1]) : "v"(a[(u + 5) % 10]), "v"(b[(u * 7) % 10]) : "vcc");
+    }
+  }
+  if ((r[0] ^ r[1]) == 0x12345) out[0] = (uint32_t)r[0];
+}
+
 // dependent chain latency: one accumulator
 __global__ void k_mad_u64_dep(uint32_t* out, uint32_t seed) {
   uint64_t r = seed ^ threadIdx.x; uint32_t a = seed, b = a * 7 + 1;
@@ -141,6 +169,7 @@ int main(int argc, char** argv) {
       {"v_mad_u32_u24", k_mad_u32_u24, 32}, {"v_mad_i32_i24", k_mad_i32_i24, 32},
       {"v_mad_u64_u32", k_mad_u64_u32, 32}, {"v_mad_u64_u32 (sgpr src)", k_mad_u64_u32_sgpr, 32},
       {"v_mad_u64_u32+v_addc (per pair)", k_mad_u64_u32_addc, 32},
+      {"v_mad_u64_u32 distinct regs/random", k_mad_u64_distinct, 32}, {"v_mad_u64_u32 2 column accumulators", k_mad_u64_column, 32},
       {"v_lshl_add_u64", k_lshl_add_u64, 32}, {"v_lshrrev_b64", k_lshrrev_b64, 32},
       {"v_fma_f32", k_fma_f32, 32}, {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"v_pk_add_u16", k_pk_add_u16, 32},
       {"v_add_f64", k_add_f64, 32}, {"v_mul_f64", k_mul_f64, 32}, {"v_fma_f64", k_fma_f64, 32},
