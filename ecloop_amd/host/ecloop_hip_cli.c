@@ -1,0 +1,773 @@
+/*
+ * ecloop-hip — host program with ecloop's command-line surface (add / mul / rnd, blf-gen / blf-check,
+ * -f -o -t -a -r -d -q -endo -seed -raw), driving MI355X GPUs through the C ABI of include/ecloop_hip.h.
+ *
+ * Plain C, links only libecloop_hip.so.  Everything here is what the reference keeps on the host side of the
+ * boundary (citations into /root/reference): filter loading (main.c:71-131), range / offset
+ * parsing (main.c:666-746), the job arithmetic of cmd_add (main.c:405-454), calc_priv (main.c:267-276),
+ * the pk_verify_hash self-check (main.c:248-263, done by re-deriving the hit on the device with the independent
+ * double-and-add kernel), the found sink and status line formats (main.c:134-203), cmd_mul's line reader
+ * (main.c:542-576), cmd_rnd's window generator (main.c:580-662), blf-gen / blf-check (utils.c:400-529).
+ * `-t N` selects the number of GPUs (one host thread per device; default: all): the scan is range-partitioned,
+ * no collective.  All curve and hash work for the search itself happens on the device.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <locale.h>
+#include <math.h>
+#include <pthread.h>
+#include <signal.h>
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include "ecloop_hip.h"
+
+#define VERSION "0.5.0-hip"
+#define GROUP_INV_SIZE 2048ull     /* main.c:17 */
+#define MAX_JOB_SIZE (2ull << 20)  /* main.c:16 */
+#define MAX_LINE_SIZE 1025         /* main.c:18 */
+#define LAUNCH_KEYS (1ull << 30)   /* keys per device call */
+#define MAX_GPUS 64
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+typedef struct { u64 w[4]; } sc; /* 256-bit scalar, little-endian limbs (the reference's fe) */
+
+/* ------------------------------------------------------------------------------------------- scalars mod n */
+static const sc SC_N = {{0xbfd25e8cd0364141ULL, 0xbaaedce6af48a03bULL, 0xfffffffffffffffeULL, ~0ULL}};
+static const sc SC_P = {{0xfffffffefffffc2fULL, ~0ULL, ~0ULL, ~0ULL}};
+static const sc SC_LAMBDA = {{0xdf02967c1b23bd72ULL, 0x122e22ea20816678ULL, 0xa5261c028812645aULL, 0x5363ad4cc05c30e0ULL}};
+
+static int sc_cmp(const sc *a, const sc *b) {
+  for (int i = 3; i >= 0; --i)
+    if (a->w[i] != b->w[i]) return a->w[i] > b->w[i] ? 1 : -1;
+  return 0;
+}
+static u64 sc_addraw(sc *r, const sc *a, const sc *b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) c += (u128)a->w[i] + b->w[i], r->w[i] = (u64)c, c >>= 64;
+  return (u64)c;
+}
+static u64 sc_subraw(sc *r, const sc *a, const sc *b) {
+  u64 br = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)a->w[i] - b->w[i] - br;
+    r->w[i] = (u64)d, br = (u64)(d >> 64) & 1;
+  }
+  return br;
+}
+static sc sc_u64(u64 v) { sc r = {{v, 0, 0, 0}}; return r; }
+static bool sc_is_zero(const sc *a) { return !(a->w[0] | a->w[1] | a->w[2] | a->w[3]); }
+static sc sc_add(sc a, sc b) { /* canonical inputs -> canonical sum */
+  sc r;
+  u64 c = sc_addraw(&r, &a, &b);
+  if (c || sc_cmp(&r, &SC_N) >= 0) sc_subraw(&r, &r, &SC_N);
+  return r;
+}
+static sc sc_neg(sc a) {
+  sc r = {{0, 0, 0, 0}};
+  if (!sc_is_zero(&a)) sc_subraw(&r, &SC_N, &a);
+  return r;
+}
+static sc sc_mul(sc a, sc b) { /* double-and-add; per hit / per job only */
+  sc r = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; --bit) {
+    r = sc_add(r, r);
+    if ((b.w[bit >> 6] >> (bit & 63)) & 1) r = sc_add(r, a);
+  }
+  return r;
+}
+static sc sc_reduce(sc a) {
+  if (sc_cmp(&a, &SC_N) >= 0) sc_subraw(&a, &a, &SC_N);
+  return a;
+}
+static sc sc_pow2(unsigned e) {
+  sc r = sc_u64(1);
+  for (unsigned i = 0; i < e; ++i) r = sc_add(r, r);
+  return r;
+}
+static unsigned sc_bitlen(const sc *a) {
+  for (int i = 3; i >= 0; --i)
+    if (a->w[i]) return 64 * i + (64 - __builtin_clzll(a->w[i]));
+  return 0;
+}
+/* fe_modn_from_hex (ecc.c:81-95,262-265): right to left, non-hex characters skipped, 64 digits at most */
+static sc sc_from_hex(const char *hex) {
+  sc r = {{0, 0, 0, 0}};
+  int cnt = 0;
+  for (long i = (long)strlen(hex) - 1; i >= 0 && cnt < 64; --i) {
+    int c = tolower((unsigned char)hex[i]);
+    u64 v;
+    if (c >= '0' && c <= '9') v = c - '0';
+    else if (c >= 'a' && c <= 'f') v = c - 'a' + 10;
+    else continue;
+    r.w[cnt / 16] |= v << (cnt * 4 % 64);
+    cnt++;
+  }
+  return sc_reduce(r);
+}
+/* calc_priv (main.c:267-276) */
+static sc calc_priv(sc start, sc stride, u64 off, int endo) {
+  sc k = sc_add(sc_reduce(start), sc_mul(stride, sc_u64(off)));
+  if (endo == 2 || endo == 3) k = sc_mul(k, SC_LAMBDA);
+  if (endo == 4 || endo == 5) k = sc_mul(sc_mul(k, SC_LAMBDA), SC_LAMBDA);
+  if (endo == 1 || endo == 3 || endo == 5) k = sc_neg(k);
+  return k;
+}
+
+/* ------------------------------------------------------------------------------------------- small utilities */
+static u64 tsnow(void) {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return (u64)tv.tv_sec * 1000 + tv.tv_usec / 1000;
+}
+typedef struct { int argc; const char **argv; } args_t;
+static bool args_bool(args_t *a, const char *name) {
+  for (int i = 1; i < a->argc; ++i)
+    if (strcmp(a->argv[i], name) == 0) return true;
+  return false;
+}
+static const char *arg_str(args_t *a, const char *name) {
+  for (int i = 1; i < a->argc - 1; ++i)
+    if (strcmp(a->argv[i], name) == 0) return a->argv[i + 1];
+  return NULL;
+}
+static u64 args_uint(args_t *a, const char *name, u64 def) {
+  const char *s = arg_str(a, name);
+  return s ? strtoull(s, NULL, 10) : def;
+}
+static void term_clear_line(void) { fputs("\033[2K\r", stderr); }
+
+/* ------------------------------------------------------------------------------------------- bloom filter (host) */
+#define BLF_MAGIC 0x45434246u
+#define BLF_VERSION 1u
+typedef struct { u64 size; u64 *bits; } blf_t;
+
+static void blf_indices(u64 idx[20], const u32 h[5]) { /* utils.c:290-306 */
+  u64 a[6] = {(u64)h[0] << 32 | h[1], (u64)h[2] << 32 | h[3], (u64)h[4] << 32 | h[0], (u64)h[1] << 32 | h[2],
+              (u64)h[3] << 32 | h[4], 0};
+  a[5] = a[0];
+  static const int S[4] = {24, 28, 36, 40};
+  for (int s = 0; s < 4; ++s)
+    for (int j = 0; j < 5; ++j) idx[s * 5 + j] = a[j] << S[s] | a[j + 1] >> S[s];
+}
+static void blf_add(blf_t *b, const u32 h[5]) {
+  u64 idx[20];
+  blf_indices(idx, h);
+  for (int i = 0; i < 20; ++i) b->bits[(idx[i] >> 6) % b->size] |= 1ULL << (idx[i] & 63);
+}
+static bool blf_has(const blf_t *b, const u32 h[5]) {
+  u64 idx[20];
+  blf_indices(idx, h);
+  for (int i = 0; i < 20; ++i)
+    if (!((b->bits[(idx[i] >> 6) % b->size] >> (idx[i] & 63)) & 1)) return false;
+  return true;
+}
+static bool blf_save(const char *path, const blf_t *b) { /* utils.c:328-360 */
+  FILE *f = fopen(path, "wb");
+  if (!f) return false;
+  u32 head[2] = {BLF_MAGIC, BLF_VERSION};
+  bool ok = fwrite(head, 4, 2, f) == 2 && fwrite(&b->size, 8, 1, f) == 1 && fwrite(b->bits, 8, b->size, f) == b->size;
+  fclose(f);
+  return ok;
+}
+static bool blf_load(const char *path, blf_t *b) { /* utils.c:362-396 */
+  FILE *f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "failed to open input file\n"); return false; }
+  u32 head[2];
+  u64 size;
+  if (fread(head, 4, 2, f) != 2 || fread(&size, 8, 1, f) != 1) {
+    fprintf(stderr, "failed to read bloom filter header\n");
+    fclose(f);
+    return false;
+  }
+  if (head[0] != BLF_MAGIC || head[1] != BLF_VERSION) {
+    fprintf(stderr, "invalid bloom filter version; create a new filter with blf-gen command\n");
+    fclose(f);
+    return false;
+  }
+  u64 *bits = calloc(size ? size : 1, 8);
+  if (fread(bits, 8, size, f) != size) {
+    fprintf(stderr, "failed to read bloom filter bits\n");
+    fclose(f);
+    free(bits);
+    return false;
+  }
+  fclose(f);
+  b->size = size, b->bits = bits;
+  return true;
+}
+static int cmp160(const void *a, const void *b) { /* addr.c:18-26 */
+  const u32 *x = a, *y = b;
+  for (int i = 0; i < 5; ++i)
+    if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
+  return 0;
+}
+static bool parse_hash40(const char *s, u32 h[5]) {
+  for (int i = 0; i < 40; ++i)
+    if (!isxdigit((unsigned char)s[i])) return false;
+  for (int j = 0; j < 5; ++j) {
+    char t[9];
+    memcpy(t, s + j * 8, 8), t[8] = 0;
+    h[j] = (u32)strtoul(t, NULL, 16);
+  }
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------- context */
+enum { CMD_NIL, CMD_ADD, CMD_MUL, CMD_RND };
+typedef struct ctx_t {
+  int cmd;
+  pthread_mutex_t lock;
+  int ngpus;
+  ecl_hip *dev[MAX_GPUS];
+  u64 k_checked, k_found;
+  bool a33, a65, endo, quiet, use_color, raw_text, has_seed, finished;
+  FILE *outfile;
+  u64 ts_started, ts_updated, ts_printed;
+  u32 *list; /* sorted unique hashes (5 words each) or NULL in bloom-only mode (main.c:49-51) */
+  u64 list_count;
+  blf_t blf;
+  sc range_s, range_e, stride_k;
+  u32 ord_offs, ord_size;
+} ctx_t;
+
+static void die_ecl(ctx_t *ctx, int g, int rc, const char *what) {
+  fprintf(stderr, "\n[!] %s: %s (%s)\n", what, ecl_hip_strerror(rc), ctx->dev[g] ? ecl_hip_last_error(ctx->dev[g]) : "");
+  exit(1);
+}
+
+/* load_filter (main.c:71-131).  fgets into a 41-byte buffer reads 40-character chunks; only full chunks count.
+   Chunks that are not clean hex are dropped (the reference parses garbage out of them). */
+static void load_filter(ctx_t *ctx, const char *path) {
+  if (!path) { fprintf(stderr, "missing filter file\n"); exit(1); }
+  FILE *f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "failed to open filter file: %s\n", path); exit(1); }
+  const char *ext = strrchr(path, '.');
+  if (ext && strcmp(ext, ".blf") == 0) {
+    fclose(f);
+    if (!blf_load(path, &ctx->blf)) exit(1);
+    return;
+  }
+  size_t cap = 32, n = 0;
+  u32 *hs = malloc(cap * 20);
+  char line[41];
+  while (fgets(line, sizeof line, f)) {
+    if (strlen(line) != 40) continue;
+    if (n >= cap) cap *= 2, hs = realloc(hs, cap * 20);
+    if (parse_hash40(line, hs + n * 5)) n++;
+  }
+  fclose(f);
+  if (n == 0) { fprintf(stderr, "no hashes in filter file\n"); exit(1); }
+  qsort(hs, n, 20, cmp160);
+  size_t u = 0;
+  for (size_t i = 1; i < n; ++i)
+    if (memcmp(hs + u * 5, hs + i * 5, 20) != 0) memcpy(hs + (++u) * 5, hs + i * 5, 20);
+  ctx->list = hs, ctx->list_count = u + 1;
+  ctx->blf.size = ctx->list_count * 2;
+  ctx->blf.bits = calloc(ctx->blf.size, 8);
+  for (size_t i = 0; i < ctx->list_count; ++i) blf_add(&ctx->blf, hs + i * 5);
+}
+
+/* status line, main.c:134-144 */
+static void ctx_print_unlocked(ctx_t *ctx) {
+  int64_t eff = (int64_t)(ctx->ts_updated - ctx->ts_started);
+  double dt = (eff < 1 ? 1 : eff) / 1000.0;
+  double it = ctx->k_checked / dt / 1000000;
+  term_clear_line();
+  fprintf(stderr, "%.2fs ~ %.2f Mkeys/s ~ %'llu / %'llu%c", dt, it, (unsigned long long)ctx->k_found,
+          (unsigned long long)ctx->k_checked, ctx->finished ? '\n' : '\r');
+  fflush(stderr);
+}
+static void ctx_update(ctx_t *ctx, u64 k) { /* main.c:158-172 */
+  u64 ts = tsnow();
+  pthread_mutex_lock(&ctx->lock);
+  ctx->k_checked += k, ctx->ts_updated = ts;
+  if (ts - ctx->ts_printed >= 100) ctx->ts_printed = ts, ctx_print_unlocked(ctx);
+  pthread_mutex_unlock(&ctx->lock);
+}
+static void ctx_finish(ctx_t *ctx) { /* main.c:174-180 */
+  pthread_mutex_lock(&ctx->lock);
+  ctx->finished = true, ctx->ts_updated = tsnow();
+  ctx_print_unlocked(ctx);
+  if (ctx->outfile) fclose(ctx->outfile);
+  pthread_mutex_unlock(&ctx->lock);
+}
+/* ctx_write_found, main.c:182-203 */
+static void ctx_write_found(ctx_t *ctx, const char *label, const u32 h[5], sc pk) {
+  pthread_mutex_lock(&ctx->lock);
+  if (!ctx->quiet) {
+    term_clear_line();
+    printf("%s: %08x%08x%08x%08x%08x <- %016llx%016llx%016llx%016llx\n", label, h[0], h[1], h[2], h[3], h[4],
+           (unsigned long long)pk.w[3], (unsigned long long)pk.w[2], (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
+    fflush(stdout);
+  }
+  if (ctx->outfile) {
+    fprintf(ctx->outfile, "%s\t%08x%08x%08x%08x%08x\t%016llx%016llx%016llx%016llx\n", label, h[0], h[1], h[2], h[3], h[4],
+            (unsigned long long)pk.w[3], (unsigned long long)pk.w[2], (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
+    fflush(ctx->outfile);
+  }
+  ctx->k_found += 1;
+  ctx_print_unlocked(ctx);
+  pthread_mutex_unlock(&ctx->lock);
+}
+/* second stage of ctx_check_hash (main.c:212-216) */
+static bool list_confirm(const ctx_t *ctx, const u32 h[5]) {
+  return !ctx->list || bsearch(h, ctx->list, ctx->list_count, 20, cmp160) != NULL;
+}
+/* pk_verify_hash (main.c:248-263): re-derive the hit from its scalar on the device (independent kernel) */
+static void pk_verify_hash(ctx_t *ctx, int g, sc pk, const u32 h[5], bool compressed, int endo) {
+  u64 k[1][4], x[1][4], y[1][4];
+  u8 ok = 0;
+  u32 h33[1][5], h65[1][5];
+  memcpy(k[0], pk.w, 32);
+  int rc = ecl_hip_diag_mulg(ctx->dev[g], k, x, y, &ok, 1);
+  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(ctx->dev[g], x, y, h33, h65, 1);
+  if (rc != ECL_OK) die_ecl(ctx, g, rc, "verify");
+  const u32 *r = compressed ? h33[0] : h65[0];
+  if (!ok || memcmp(r, h, 20) != 0) {
+    fprintf(stderr, "[!] error: hash mismatch (compressed: %d endo: %d)\n", compressed, endo);
+    fprintf(stderr, "pk: %016llx%016llx%016llx%016llx\n", (unsigned long long)pk.w[3], (unsigned long long)pk.w[2],
+            (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
+    fprintf(stderr, "lh: %08x%08x%08x%08x%08x\n", h[0], h[1], h[2], h[3], h[4]);
+    fprintf(stderr, "rh: %08x%08x%08x%08x%08x\n", r[0], r[1], r[2], r[3], r[4]);
+    exit(1);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- add */
+typedef struct { ctx_t *ctx; int g; sc start; u64 nkeys; u64 status_total, keys_total; } add_job;
+
+/* hash `nkeys` keys from `start` on GPU g in launches of LAUNCH_KEYS, report hits */
+static void *add_worker(void *arg) {
+  add_job *j = arg;
+  ctx_t *ctx = j->ctx;
+  u32 cap = 4096;
+  ecl_found *buf = malloc(sizeof(ecl_found) * cap);
+  for (u64 done = 0; done < j->nkeys;) {
+    u64 n = j->nkeys - done < LAUNCH_KEYS ? j->nkeys - done : LAUNCH_KEYS;
+    sc s = sc_add(sc_reduce(j->start), sc_mul(ctx->stride_k, sc_u64(done)));
+    u32 cnt = 0;
+    int rc;
+    for (;;) {
+      rc = ecl_hip_add_range(ctx->dev[j->g], s.w, n, buf, cap, &cnt);
+      if (rc != ECL_E_OVERFLOW) break;
+      cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap); /* dense filter: rerun with a buffer that fits */
+    }
+    if (rc != ECL_OK) die_ecl(ctx, j->g, rc, "add_range");
+    for (u32 i = 0; i < cnt; ++i) {
+      if (!list_confirm(ctx, buf[i].h160)) continue;
+      sc pk = calc_priv(s, ctx->stride_k, buf[i].key_offset, buf[i].endo);
+      pk_verify_hash(ctx, j->g, pk, buf[i].h160, buf[i].compressed, buf[i].endo);
+      ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pk);
+    }
+    done += n;
+    /* status counter: the reference adds job_size (x6 with endo) per job (main.c:431); spread it over the launches */
+    u64 before = (u64)((u128)j->status_total * (done - n) / j->keys_total);
+    u64 after = (u64)((u128)j->status_total * done / j->keys_total);
+    ctx_update(ctx, after - before);
+  }
+  free(buf);
+  return NULL;
+}
+
+/* cmd_add (main.c:437-454) over [range_s, range_e): same keys hashed, same counters, sharded over the GPUs */
+static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
+  sc span;
+  sc_subraw(&span, &re, &rs);
+  /* cmd_rnd always uses MAX_JOB_SIZE jobs, even for a narrower window (main.c:624) */
+  bool small = !full_jobs && !(span.w[1] | span.w[2] | span.w[3]) && span.w[0] < MAX_JOB_SIZE;
+  u64 job = small ? span.w[0] : MAX_JOB_SIZE; /* main.c:442 */
+  /* njobs = ceil(span / (job * stride)) (main.c:420-427): count by stepping like the reference's counter */
+  sc inc = sc_mul(ctx->stride_k, sc_u64(job));
+  u64 njobs = 0;
+  if (small && ctx->ord_offs == 0) njobs = 1;
+  else {
+    /* span / (job*stride): both are < 2^256; do it by long division on the top 128 bits when stride is a power of two */
+    sc cur = rs;
+    /* fast path: job*stride = 2^(21+offs) (job = 2^21) or small job: iterate at most a few steps */
+    if (!small) {
+      unsigned sh = 21 + ctx->ord_offs;
+      if (sh >= 256) njobs = 1;
+      else {
+        /* njobs = ceil(span / 2^sh) */
+        sc q = {{0, 0, 0, 0}};
+        for (unsigned b = sh; b < 256; ++b)
+          if ((span.w[b >> 6] >> (b & 63)) & 1) q.w[(b - sh) >> 6] |= 1ULL << ((b - sh) & 63);
+        bool rem = false;
+        for (unsigned b = 0; b < sh; ++b)
+          if ((span.w[b >> 6] >> (b & 63)) & 1) rem = true;
+        if (q.w[1] | q.w[2] | q.w[3]) { fprintf(stderr, "range too large for one run: narrow -r or raise -d\n"); exit(1); }
+        njobs = q.w[0] + (rem ? 1 : 0);
+      }
+    } else {
+      while (sc_cmp(&cur, &re) < 0 && njobs < (1u << 20)) {
+        sc nx;
+        if (sc_addraw(&nx, &cur, &inc)) { njobs++; break; }
+        cur = nx, njobs++;
+      }
+    }
+  }
+  u64 per_job = (job + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
+  u64 hashed = (njobs - 1) * job + per_job; /* contiguous run of keys actually hashed */
+  u64 status_total = njobs * job * (ctx->endo ? 6 : 1);
+  int ng = ctx->ngpus;
+  u64 per = (hashed + ng - 1) / ng;
+  per = (per + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
+  pthread_t th[MAX_GPUS];
+  add_job jobs[MAX_GPUS];
+  int started = 0;
+  u64 status_given = 0;
+  for (int g = 0; g < ng; ++g) {
+    u64 lo = (u64)g * per < hashed ? (u64)g * per : hashed;
+    u64 hi = lo + per < hashed ? lo + per : hashed;
+    if (hi == lo) continue;
+    u64 st_hi = (u64)((u128)status_total * hi / hashed);
+    jobs[started] = (add_job){ctx, g, sc_add(sc_reduce(rs), sc_mul(ctx->stride_k, sc_u64(lo))), hi - lo, st_hi - status_given, hi - lo};
+    status_given = st_hi;
+    pthread_create(&th[started], NULL, add_worker, &jobs[started]);
+    started++;
+  }
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+}
+
+static void cmd_add(ctx_t *ctx) {
+  ctx->ts_started = tsnow();
+  scan_range(ctx, ctx->range_s, ctx->range_e, false);
+  ctx_finish(ctx);
+}
+
+/* ------------------------------------------------------------------------------------------- mul */
+/* host SHA-256 of a passphrase for `-raw` (main.c:505-527): input preparation, not the search path */
+static void sha256_host(u32 st[8], const u8 *msg, size_t len) {
+  static const u32 K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  static const u32 IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  size_t total = (len + 9 + 63) / 64 * 64;
+  u8 *buf = calloc(total, 1);
+  memcpy(buf, msg, len);
+  buf[len] = 0x80;
+  for (int j = 0; j < 8; ++j) buf[total - 1 - j] = (u8)(((u64)len * 8) >> (8 * j));
+  memcpy(st, IV, 32);
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+  for (size_t off = 0; off < total; off += 64) {
+    u32 w[64], v[8];
+    for (int i = 0; i < 16; ++i)
+      w[i] = (u32)buf[off + 4 * i] << 24 | (u32)buf[off + 4 * i + 1] << 16 | (u32)buf[off + 4 * i + 2] << 8 | buf[off + 4 * i + 3];
+    for (int i = 16; i < 64; ++i)
+      w[i] = w[i - 16] + (ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
+             (ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    memcpy(v, st, 32);
+    for (int i = 0; i < 64; ++i) {
+      u32 t1 = v[7] + (ROR(v[4], 6) ^ ROR(v[4], 11) ^ ROR(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K[i] + w[i];
+      u32 t2 = (ROR(v[0], 2) ^ ROR(v[0], 13) ^ ROR(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+      memmove(v + 1, v, 28);
+      v[4] += t1, v[0] = t1 + t2;
+    }
+    for (int i = 0; i < 8; ++i) st[i] += v[i];
+  }
+#undef ROR
+  free(buf);
+}
+
+static void mul_flush(ctx_t *ctx, u64 (*ks)[4], u32 n) {
+  if (!n) return;
+  u32 cap = n * 2 + 16, cnt = 0;
+  ecl_found *buf = malloc(sizeof(ecl_found) * cap);
+  int rc = ecl_hip_mul_batch(ctx->dev[0], ks, n, buf, cap, &cnt);
+  if (rc != ECL_OK) die_ecl(ctx, 0, rc, "mul_batch");
+  for (u32 i = 0; i < cnt; ++i) {
+    if (!list_confirm(ctx, buf[i].h160)) continue;
+    sc pk;
+    memcpy(pk.w, ks[buf[i].key_offset], 32);
+    ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pk); /* no verify: main.c:469,474 */
+  }
+  free(buf);
+  ctx_update(ctx, n);
+}
+/* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches */
+static void cmd_mul(ctx_t *ctx) {
+  ctx->ts_started = tsnow();
+  const u32 BATCH = 1u << 16;
+  u64(*ks)[4] = malloc((size_t)BATCH * 32);
+  u32 n = 0;
+  char line[MAX_LINE_SIZE];
+  while (fgets(line, sizeof line, stdin)) {
+    size_t len = strlen(line);
+    if (len && line[len - 1] == '\n') line[--len] = 0;
+    if (len && line[len - 1] == '\r') line[--len] = 0;
+    if (!len) continue;
+    sc k;
+    if (!ctx->raw_text) k = sc_from_hex(line);
+    else {
+      u32 st[8];
+      sha256_host(st, (const u8 *)line, len);
+      k.w[0] = (u64)st[6] << 32 | st[7], k.w[1] = (u64)st[4] << 32 | st[5];
+      k.w[2] = (u64)st[2] << 32 | st[3], k.w[3] = (u64)st[0] << 32 | st[1];
+    }
+    memcpy(ks[n++], k.w, 32);
+    if (n == BATCH) mul_flush(ctx, ks, n), n = 0;
+  }
+  mul_flush(ctx, ks, n);
+  free(ks);
+  ctx_finish(ctx);
+}
+
+/* ------------------------------------------------------------------------------------------- rnd */
+static u64 rand64(bool urandom) { /* utils.c:83-113 */
+  u64 r = 0;
+  if (urandom) {
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f || fread(&r, 8, 1, f) != 1) { fprintf(stderr, "failed to read /dev/urandom\n"); exit(1); }
+    fclose(f);
+    return r;
+  }
+  return (u64)rand() << 32 | (u64)rand();
+}
+static sc sc_rand_range(const sc *a, const sc *b, bool urandom) { /* uniform-ish value in [a, b) (utils.c:115-153) */
+  sc span, r;
+  sc_subraw(&span, b, a);
+  unsigned bits = sc_bitlen(&span);
+  for (;;) {
+    for (int i = 0; i < 4; ++i) r.w[i] = rand64(urandom);
+    for (unsigned i = bits; i < 256; ++i) r.w[i >> 6] &= ~(1ULL << (i & 63));
+    if (sc_cmp(&r, &span) < 0) break;
+  }
+  sc_addraw(&r, &r, a);
+  return r;
+}
+static void print_range_mask(const sc *v, u32 bits_size, u32 offset, bool color) { /* main.c:593-617 */
+  int mask_e = 255 - (int)offset, mask_s = mask_e - (int)bits_size + 1;
+  for (int i = 0; i < 64; i++) {
+    if (i % 16 == 0 && i != 0) putchar(' ');
+    int bs = i * 4, be = bs + 3;
+    u32 nib = (v->w[(255 - be) / 64] >> ((255 - be) % 64)) & 0xF;
+    bool flag = (bs >= mask_s && bs <= mask_e) || (be >= mask_s && be <= mask_e);
+    if (flag && color) fputs("\033[33m", stdout);
+    putchar("0123456789abcdef"[nib]);
+    if (flag && color) fputs("\033[0m", stdout);
+  }
+  putchar('\n');
+}
+/* cmd_rnd (main.c:619-662): random value in [A,B], bits offs..offs+size-1 cleared / set -> window, scanned like add */
+static void cmd_rnd(ctx_t *ctx) {
+  if (ctx->ord_offs > 255 - ctx->ord_size) ctx->ord_offs = 255 - ctx->ord_size;
+  printf("[RANDOM MODE] offs: %d ~ bits: %d\n\n", ctx->ord_offs, ctx->ord_size);
+  ctx->ts_started = tsnow();
+  sc a = ctx->range_s, b = ctx->range_e;
+  for (;;) {
+    u64 last_c = ctx->k_checked, last_f = ctx->k_found, t0 = tsnow();
+    sc s = sc_rand_range(&a, &b, !ctx->has_seed), e = s; /* gen_random_range, main.c:580-591 */
+    for (u32 i = ctx->ord_offs; i < ctx->ord_offs + ctx->ord_size; ++i) s.w[i / 64] &= ~(1ULL << (i % 64)), e.w[i / 64] |= 1ULL << (i % 64);
+    if (sc_cmp(&s, &a) <= 0) s = a;
+    if (sc_cmp(&e, &b) >= 0) e = b;
+    print_range_mask(&s, ctx->ord_size, ctx->ord_offs, ctx->use_color);
+    print_range_mask(&e, ctx->ord_size, ctx->ord_offs, ctx->use_color);
+    bool is_full = sc_cmp(&s, &a) == 0 && sc_cmp(&e, &b) == 0;
+    if (sc_cmp(&s, &e) < 0) scan_range(ctx, s, e, true);
+    u64 dc = ctx->k_checked - last_c, df = ctx->k_found - last_f;
+    double dt = (tsnow() - t0 < 1 ? 1 : tsnow() - t0) / 1000.0;
+    term_clear_line();
+    printf("%'llu / %'llu ~ %.1fs\n\n", (unsigned long long)df, (unsigned long long)dc, dt);
+    if (is_full) break;
+  }
+  ctx_finish(ctx);
+}
+
+/* ------------------------------------------------------------------------------------------- blf-gen / blf-check */
+static void blf_gen(args_t *args) { /* utils.c:409-475 */
+  u64 n = args_uint(args, "-n", 0);
+  const char *path = arg_str(args, "-o");
+  if (!n || !path) {
+    fprintf(stderr, "Usage: %s blf-gen -n <count> -o <file>   (hex hash160 list on stdin)\n", args->argv[0]);
+    exit(1);
+  }
+  u64 r = 1000000000ull;
+  double p = 1.0 / (double)r;
+  u64 m = (u64)(n * log(p) / log(1.0 / pow(2.0, log(2.0))));
+  double mb = (double)m / 8 / 1024 / 1024;
+  u64 size = (m + 63) / 64;
+  blf_t blf = {0, NULL};
+  if (access(path, F_OK) == 0) {
+    printf("file %s already exists; loading...\n", path);
+    if (!blf_load(path, &blf)) { fprintf(stderr, "[!] failed to load bloom filter: delete it or choose a different file\n"); exit(1); }
+    if (blf.size != size) { fprintf(stderr, "[!] bloom filter size mismatch (%'llu != %'llu)\n", (unsigned long long)blf.size, (unsigned long long)size); exit(1); }
+    printf("updating bloom filter...\n");
+  } else {
+    printf("creating bloom filter...\n");
+    blf.size = size, blf.bits = calloc(size, 8);
+  }
+  printf("bloom filter params: n = %'llu | p = 1:%'llu | m = %'llu (%'.1f MB)\n", (unsigned long long)n, (unsigned long long)r, (unsigned long long)m, mb);
+  u64 count = 0;
+  char line[41];
+  while (fgets(line, sizeof line, stdin)) {
+    u32 h[5];
+    if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
+    if (blf_has(&blf, h)) continue;
+    blf_add(&blf, h), count++;
+  }
+  printf("added %'llu new items; saving to %s\n", (unsigned long long)count, path);
+  if (!blf_save(path, &blf)) { fprintf(stderr, "[!] failed to save bloom filter\n"); exit(1); }
+}
+static void blf_check(args_t *args) { /* utils.c:495-529 */
+  const char *path = arg_str(args, "-f");
+  blf_t blf = {0, NULL};
+  if (!path || !blf_load(path, &blf)) { fprintf(stderr, "Usage: %s blf-check -f <file> <hash> [hash...]\n", args->argv[0]); exit(1); }
+  bool any = false;
+  for (int i = 1; i < args->argc; ++i) {
+    u32 h[5];
+    if (strlen(args->argv[i]) != 40 || !parse_hash40(args->argv[i], h)) continue;
+    any = true;
+    printf("%s %s\n", args->argv[i], blf_has(&blf, h) ? "FOUND" : "NOT FOUND");
+  }
+  if (any) return;
+  char line[128];
+  while (fgets(line, sizeof line, stdin)) {
+    line[strcspn(line, "\r\n")] = 0;
+    u32 h[5];
+    if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
+    printf("%s %s\n", line, blf_has(&blf, h) ? "FOUND" : "NOT FOUND");
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- argument handling */
+static void arg_search_range(args_t *args, sc *rs, sc *re) { /* main.c:666-701 */
+  const char *raw = arg_str(args, "-r");
+  if (!raw) { *rs = sc_u64(GROUP_INV_SIZE), *re = SC_P; return; }
+  char *tmp = strdup(raw), *sep = strchr(tmp, ':');
+  if (!sep) { fprintf(stderr, "invalid search range, use format: -r 8000:ffff\n"); exit(1); }
+  *sep = 0;
+  *rs = sc_from_hex(tmp), *re = sc_from_hex(sep + 1);
+  free(tmp);
+  sc lim = sc_u64(GROUP_INV_SIZE);
+  if (sc_cmp(rs, &lim) <= 0) { fprintf(stderr, "invalid search range, start <= %#llx\n", (unsigned long long)GROUP_INV_SIZE); exit(1); }
+  if (sc_cmp(re, &SC_P) > 0) { fprintf(stderr, "invalid search range, end > FE_P\n"); exit(1); }
+  if (sc_cmp(rs, re) >= 0) { fprintf(stderr, "invalid search range, start >= end\n"); exit(1); }
+}
+static void load_offs_size(ctx_t *ctx, args_t *args) { /* main.c:703-746 */
+  const u32 MIN_SIZE = 20, MAX_SIZE = 64;
+  u32 range_bits = sc_bitlen(&ctx->range_e);
+  u32 default_bits = range_bits < 32 ? (MIN_SIZE > range_bits ? MIN_SIZE : range_bits) : 32;
+  u32 mx = MIN_SIZE > range_bits ? MIN_SIZE : range_bits;
+  u32 max_offs = mx - default_bits > 1 ? mx - default_bits : 1;
+  const char *raw = arg_str(args, "-d");
+  if (!raw) {
+    ctx->ord_offs = ctx->cmd == CMD_RND ? (u32)(rand64(!ctx->has_seed) % max_offs) : 0;
+    ctx->ord_size = default_bits;
+    return;
+  }
+  const char *sep = strchr(raw, ':');
+  if (!sep) { fprintf(stderr, "invalid offset:size format, use format: -d 128:32\n"); exit(1); }
+  u32 offs = (u32)atoi(raw), size = (u32)atoi(sep + 1);
+  if (offs > 255) { fprintf(stderr, "invalid offset, max is 255\n"); exit(1); }
+  if (size < MIN_SIZE || size > MAX_SIZE) { fprintf(stderr, "invalid size, min is %d and max is %d\n", MIN_SIZE, MAX_SIZE); exit(1); }
+  ctx->ord_offs = offs < max_offs ? offs : max_offs;
+  ctx->ord_size = size;
+}
+static void usage(const char *name) { /* main.c:750-772 */
+  printf("Usage: %s <cmd> [-t <gpus>] [-f <file>] [-a <addr_type>] [-r <range>]\n", name);
+  printf("v%s ~ MI355X build of the ecloop command set\n", VERSION);
+  printf("\nCompute commands:\n");
+  printf("  add             - search in given range with batch addition\n");
+  printf("  mul             - search hex encoded private keys (from stdin)\n");
+  printf("  rnd             - search random range of bits in given range\n");
+  printf("\nCompute options:\n");
+  printf("  -f <file>       - filter file to search (list of hashes or bloom fitler)\n");
+  printf("  -o <file>       - output file to write found keys (default: stdout)\n");
+  printf("  -t <gpus>       - number of GPUs to use (default: all)\n");
+  printf("  -a <addr_type>  - address type to search: c - addr33, u - addr65 (default: c)\n");
+  printf("  -r <range>      - search range in hex format (example: 8000:ffff, default all)\n");
+  printf("  -d <offs:size>  - bit offset and size for search (example: 128:32, default: 0:32)\n");
+  printf("  -q              - quiet mode (no output to stdout; -o required)\n");
+  printf("  -endo           - use endomorphism (default: false)\n");
+  printf("\nOther commands:\n");
+  printf("  blf-gen         - create bloom filter from list of hex-encoded hash160\n");
+  printf("  blf-check       - check bloom filter for given hex-encoded hash160\n\n");
+}
+static void handle_sigint(int sig) {
+  fflush(stderr), fflush(stdout);
+  printf("\n");
+  exit(sig);
+}
+
+int main(int argc, const char **argv) {
+  setlocale(LC_NUMERIC, "");
+  args_t args = {argc, argv};
+  static ctx_t ctx;
+  if (argc > 1) {
+    if (!strcmp(argv[1], "blf-gen")) return blf_gen(&args), 0;
+    if (!strcmp(argv[1], "blf-check")) return blf_check(&args), 0;
+    if (!strcmp(argv[1], "add")) ctx.cmd = CMD_ADD;
+    if (!strcmp(argv[1], "mul")) ctx.cmd = CMD_MUL;
+    if (!strcmp(argv[1], "rnd")) ctx.cmd = CMD_RND;
+  }
+  if (ctx.cmd == CMD_NIL) {
+    if (args_bool(&args, "-v")) printf("ecloop-hip v%s\n", VERSION);
+    else usage(argv[0]);
+    return 0;
+  }
+  ctx.use_color = isatty(fileno(stdout));
+  const char *seed = arg_str(&args, "-seed");
+  if (seed) {
+    u32 s = 5381;
+    for (const char *c = seed; *c; ++c) s = s * 33 + (u8)*c;
+    ctx.has_seed = true, srand(s); /* the reference free()s an argv pointer here and aborts (main.c:800-805) */
+  }
+  load_filter(&ctx, arg_str(&args, "-f"));
+  ctx.quiet = args_bool(&args, "-q");
+  const char *outfile = arg_str(&args, "-o");
+  if (outfile) ctx.outfile = fopen(outfile, "a");
+  if (!outfile && ctx.quiet) { fprintf(stderr, "quiet mode chosen without output file\n"); return 1; }
+  const char *addr = arg_str(&args, "-a");
+  if (addr) ctx.a33 = strchr(addr, 'c') != NULL, ctx.a65 = strchr(addr, 'u') != NULL;
+  if (!ctx.a33 && !ctx.a65) ctx.a33 = true;
+  ctx.endo = args_bool(&args, "-endo") && ctx.cmd != CMD_MUL;
+  ctx.raw_text = args_bool(&args, "-raw");
+  pthread_mutex_init(&ctx.lock, NULL);
+  ctx.ts_started = ctx.ts_updated = tsnow();
+  ctx.ts_printed = ctx.ts_started - 5000;
+  arg_search_range(&args, &ctx.range_s, &ctx.range_e);
+  load_offs_size(&ctx, &args);
+  ctx.stride_k = sc_pow2(ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
+
+  int have = ecl_hip_device_count();
+  if (have <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
+  u64 want = args_uint(&args, "-t", (u64)have);
+  ctx.ngpus = (int)(want < 1 ? 1 : want > (u64)have ? (u64)have : want);
+  if (ctx.ngpus > MAX_GPUS) ctx.ngpus = MAX_GPUS;
+  if (ctx.cmd == CMD_MUL) ctx.ngpus = 1;
+  u32 flags = (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0);
+  for (int g = 0; g < ctx.ngpus; ++g) {
+    int rc = ecl_hip_open(&ctx.dev[g], g, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx.dev[g], ctx.blf.bits, ctx.blf.size);
+    if (rc != ECL_OK) die_ecl(&ctx, g, rc, "open");
+  }
+  printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", ctx.ngpus, ctx.a33, ctx.a65, ctx.endo);
+  if (ctx.list) printf("list (%'llu)\n", (unsigned long long)ctx.list_count);
+  else printf("bloom\n");
+  if (ctx.cmd == CMD_ADD) {
+    printf("range_s: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_s.w[3], (unsigned long long)ctx.range_s.w[2], (unsigned long long)ctx.range_s.w[1], (unsigned long long)ctx.range_s.w[0]);
+    printf("range_e: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_e.w[3], (unsigned long long)ctx.range_e.w[2], (unsigned long long)ctx.range_e.w[1], (unsigned long long)ctx.range_e.w[0]);
+  }
+  printf("----------------------------------------\n");
+  fflush(stdout);
+  signal(SIGINT, handle_sigint);
+  if (ctx.cmd == CMD_ADD) cmd_add(&ctx);
+  if (ctx.cmd == CMD_MUL) cmd_mul(&ctx);
+  if (ctx.cmd == CMD_RND) cmd_rnd(&ctx);
+  for (int g = 0; g < ctx.ngpus; ++g) ecl_hip_close(ctx.dev[g]);
+  return 0;
+}

@@ -1,0 +1,143 @@
+"""The C host program (ecloop_amd/host/ecloop-hip): blf-gen / blf-check on the CPU, the search commands on the GPU,
+against the reference's golden outputs (same flags, same output formats, same status counters)."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from synth import synth_bloom_words, write_blf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+G = json.load(open(os.path.join(GOLD, "golden.json")))["cases"]
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from ecloop_amd.build import build_host_cli, build_library
+    build_library()
+    return build_host_cli()
+
+
+def run(cli, args, stdin_path=None, out=None):
+    cmd = [cli] + args + (["-q", "-o", out] if out else [])
+    pr = subprocess.run(cmd, stdin=open(stdin_path, "rb") if stdin_path else subprocess.DEVNULL, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=600)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
+    status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
+    lines = sorted(l.rstrip("\n") for l in open(out)) if out and os.path.exists(out) else []
+    return lines, status, pr.stdout.decode(errors="replace")
+
+
+def counts(status):
+    found, checked = status.split("~")[-1].split("/")
+    clean = lambda s: int("".join(c for c in s if c.isdigit()))
+    return clean(found), clean(checked)
+
+
+def digest(lines):
+    return hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest()
+
+
+def test_blf_gen_and_check_byte_exact(cli, tmp_path):
+    """`make blf` flow (Makefile:35-44): create, then update in place; file identical to the reference's."""
+    out = str(tmp_path / "p.blf")
+    g = G["blf_gen_puzzles_32768"]
+    for expect in ("creating bloom filter", "updating bloom filter"):
+        pr = subprocess.run([cli, "blf-gen", "-n", "32768", "-o", out], stdin=open(os.path.join(GOLD, "btc-puzzles-hash"), "rb"),
+                            stdout=subprocess.PIPE, check=True)
+        assert expect in pr.stdout.decode()
+        raw = open(out, "rb").read()
+        assert len(raw) == g["bytes"] and hashlib.sha256(raw).hexdigest() == g["sha256"]
+    assert "added 0 new items" in pr.stdout.decode()
+    h = open(os.path.join(GOLD, "btc-puzzles-hash")).readline().strip()
+    pr = subprocess.run([cli, "blf-check", "-f", out, h, "00" * 20], stdout=subprocess.PIPE, check=True)
+    assert pr.stdout.decode().splitlines() == [h + " FOUND", "00" * 20 + " NOT FOUND"]
+
+
+def test_usage_and_version(cli):
+    assert "ecloop-hip v" in subprocess.run([cli, "-v"], stdout=subprocess.PIPE).stdout.decode()
+    assert "blf-gen" in subprocess.run([cli], stdout=subprocess.PIPE).stdout.decode()
+    pr = subprocess.run([cli, "add", "-f", os.path.join(GOLD, "btc-puzzles-hash"), "-r", "800:ffff"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE)
+    assert pr.returncode == 1 and b"invalid search range" in pr.stderr
+
+
+@pytest.mark.gpu
+def test_add_known_answers(cli, tmp_path):
+    puz = os.path.join(GOLD, "btc-puzzles-hash")
+    for name, rng, extra in [("cfg1_list_800000_ffffff", "800000:ffffff", []), ("make_add_8000_ffffff", "8000:ffffff", []),
+                             ("ci_smoke_8000_ffff", "8000:ffff", []), ("endo_cu_list_8000_fffff", "8000:fffff", ["-a", "cu", "-endo"])]:
+        lines, status, _ = run(cli, ["add", "-f", puz, "-r", rng, "-t", "1"] + extra, out=str(tmp_path / (name + ".txt")))
+        g = G[name]
+        assert lines == sorted(g["lines"])
+        assert counts(status) == (g["status_found"], g["status_checked"])
+
+
+@pytest.mark.gpu
+def test_add_dumps_and_stride(cli, tmp_path):
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    a = (1 << 164) + 0x12345
+    for name, args in [("dump33_8000_87ff", ["-r", "8000:87ff"]), ("dump65_8000_87ff", ["-r", "8000:87ff", "-a", "u"]),
+                       ("dump_cu_endo_8000_87ff", ["-r", "8000:87ff", "-a", "cu", "-endo"]),
+                       ("dump33_overrun_9000_9801", ["-r", "9000:9801"]),
+                       ("dump33_stride128", ["-r", f"{a:x}:{a + 1:x}", "-d", "128:32"])]:
+        lines, status, _ = run(cli, ["add", "-f", ones, "-t", "1"] + args, out=str(tmp_path / (name + ".txt")))
+        g = G[name]
+        assert len(lines) == g["count"] and digest(lines) == g["sha256_sorted"], name
+        assert counts(status) == (g["status_found"], g["status_checked"]), name
+
+
+@pytest.mark.gpu
+def test_sparse_bloom_two_jobs(cli, tmp_path):
+    g = G["sparse_fp33_two_jobs"]
+    blf = str(tmp_path / "s.blf")
+    write_blf(blf, synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"]))
+    lines, status, _ = run(cli, ["add", "-f", blf, "-r", "8000:208800"], out=str(tmp_path / "o.txt"))
+    assert digest(lines) == g["sha256_sorted"] and counts(status) == (g["status_found"], g["status_checked"])
+
+
+@pytest.mark.gpu
+def test_mul_flows(cli, tmp_path):
+    lines, status, _ = run(cli, ["mul", "-f", os.path.join(GOLD, "btc-bw-hash"), "-a", "cu"], stdin_path=os.path.join(GOLD, "btc-bw-priv"),
+                           out=str(tmp_path / "m.txt"))
+    g = G["make_mul_bw"]
+    assert len(lines) == 1080 and digest(lines) == g["sha256_sorted"] and counts(status) == (1080, 1080)
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    lines, _, _ = run(cli, ["mul", "-f", ones, "-a", "cu"], stdin_path=os.path.join(GOLD, "mul_scalars.txt"), out=str(tmp_path / "d.txt"))
+    assert digest(lines) == G["mul_dump_cu"]["sha256_sorted"]
+    # -raw: scalar = SHA-256(line); "abc" is a public SHA-256 test vector
+    raw = tmp_path / "raw.txt"
+    raw.write_text("abc\n")
+    lines, _, _ = run(cli, ["mul", "-f", ones, "-raw"], stdin_path=str(raw), out=str(tmp_path / "r.txt"))
+    assert lines[0].split("\t")[2] == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+
+
+@pytest.mark.gpu
+def test_rnd_window_is_an_add_over_the_printed_bounds(cli, tmp_path):
+    """a random window equals `add -r range_s:range_e -d offs:size` on the printed bounds."""
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, synth_bloom_words(4099, seed=11, mode="a|b"))
+    out = str(tmp_path / "rnd.txt")
+    # range = one window wide, so the first window is the full range and rnd stops after it (main.c:643,658)
+    lo, hi = 1 << 40, (1 << 40) + (1 << 20) - 1
+    pr = subprocess.run([cli, "rnd", "-f", ones, "-r", f"{lo:x}:{hi:x}", "-d", "0:20", "-q", "-o", out], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode == 0, pr.stderr.decode()[-1000:]
+    text = pr.stdout.decode()
+    assert "[RANDOM MODE] offs: 0 ~ bits: 20" in text
+    masks = [l.replace(" ", "") for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
+    assert int(masks[0], 16) == lo and int(masks[1], 16) == hi
+    rnd_lines = sorted(l.rstrip("\n") for l in open(out))
+    add_out = str(tmp_path / "add.txt")
+    add_lines, _, _ = run(cli, ["add", "-f", ones, "-r", f"{lo:x}:{hi:x}"], out=add_out)
+    # rnd scans whole 2^21-key jobs (main.c:624): the add over the same bounds is a subset; same keys inside the window
+    inside = [l for l in rnd_lines if lo <= int(l.split("\t")[2], 16) <= hi + 2048]
+    assert set(add_lines) <= set(rnd_lines) and len(add_lines) > 100
+    assert all(int(l.split("\t")[2], 16) < lo + (1 << 21) for l in rnd_lines)
