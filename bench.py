@@ -58,8 +58,9 @@ def build_filter(dev, start, nkeys):
     dev.bloom_insert(splitmix_hashes(FILTER_N, 2025))
     offs = [(nkeys // PLANTED) * i + 12345 * (i + 1) % 4096 for i in range(PLANTED)]
     xs, ys, ok = dev.diag_mulg([start + o for o in offs])
-    h33, _ = dev.diag_hash160(xs, ys)
+    h33, h65 = dev.diag_hash160(xs, ys)
     dev.bloom_insert(h33)
+    dev.bloom_insert(h65)
     return size, offs, h33
 
 
@@ -132,6 +133,8 @@ def main():
     ap.add_argument("--half-group", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--addr", default="c", choices=["c", "u", "cu"], help="non-headline variants: -a u / -a cu")
+    ap.add_argument("--endo", action="store_true", help="non-headline variant: -endo (6 images per key)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,10 +154,12 @@ def main():
     start = RANGE_A + rank * nkeys
 
     # --- inputs -> HBM (untimed)
-    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33=True, verify=True,
+    headline = args.addr == "c" and not args.endo
+    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr,
+                   endo=args.endo, verify=True,
                    launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
     size, planted_offs, planted_h = build_filter(ks.dev, start, nkeys)
-    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu) else None
+    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
 
     def barrier():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -201,7 +206,7 @@ def main():
     keys_per_launch = kkeys / max(launches, 1)
     achieved = keys_per_launch * OPS_PER_KEY / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
     res = {
-        "metric": "Mkeys/sec (add, addr33)", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
+        "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"add addr33, 2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}, "
@@ -213,7 +218,13 @@ def main():
                      "kernel": "k_add<addr33>", "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch),
                      "ops_per_key": OPS_PER_KEY, "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0},
     }
-    if world == 1 and not args.no_cpu:
+    if not headline:
+        hashes_per_key = len(args.addr) * (6 if args.endo else 1)
+        res["config"]["workload"] = res["config"]["workload"].replace("add addr33", f"add -a {args.addr}{' -endo' if args.endo else ''}")
+        res["config"]["hashes_per_key"] = hashes_per_key
+        res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: algorithmic op count not priced", "ms_per_launch": round(ms_launch, 3),
+                           "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(value * hashes_per_key / 1e3, 2)}
+    if world == 1 and not args.no_cpu and headline:
         cb, (log2n, cpu_lines) = cpu_baseline(words)
         res["cpu_baseline"] = cb
         gpu_lines = sorted(r.line() for r in ks.found if r.pk < RANGE_A + (1 << log2n))

@@ -49,16 +49,38 @@ __global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0
   fe_st_words2(cxy + 2 * (size_t)T + g, T, y);
 }
 
-// `mul` command body: public key of each scalar, hash, probe (main.c:530-534, 458-479)
+// `mul` command body (main.c:530-534, 458-479): public key of each scalar by the fixed-base window method of
+// ec_gtable_mul (lib/ecc.c:876-929: W = 14, 19 windows, table slot (2^14-1)*i + b-1 = b * 2^(14 i) * G), then
+// hash + probe.  One lane = one scalar: <= 19 mixed additions of table points (64-byte gathers, the 19.9 MB table
+// lives in L2 / Infinity Cache) and one inversion.  The scalar 0 yields no point (the reference emits garbage).
+#define GT_W 14u
+#define GT_WINDOWS 19u
+#define GT_PER ((1u << GT_W) - 1u)
 template <bool A33, bool A65>
-__global__ void __launch_bounds__(64) k_mul_check(const u32* __restrict__ k, u32 n, add_args a) {
-  u32 i = blockIdx.x * 64u + threadIdx.x;
+__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, const u32* __restrict__ gtab, add_args a) {
+  u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  u32 kk[8];
+  u32 kk[9];
 #pragma unroll
   for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
+  kk[8] = 0;
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#pragma unroll 1
+  for (u32 w = 0; w < GT_WINDOWS; ++w) {
+    const u32 bit = w * GT_W, word = bit >> 5, sh = bit & 31;
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
+      if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+    }
+    const u32 digit = (u32)((((u64)hi << 32 | lo) >> sh) & GT_PER);
+    if (!digit) continue;
+    const u32* e = gtab + ((size_t)w * GT_PER + digit - 1) * 16;
+    acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
+  }
   fe x, y;
-  if (!ec_mul_g_affine(x, y, kk)) return;
+  if (!jac_to_affine(x, y, acc)) return;
   check_point<A33, A65, false>(a, x, y, (u64)i);
 }
 
@@ -125,6 +147,7 @@ struct ecl_hip {
   std::string err;
   // device buffers
   u32* d_tab = nullptr;  u32 tab_B = 0;        // table for (B, offs)
+  u32* d_gtab = nullptr;                       // fixed-base window table for `mul` (19 x 16383 affine points)
   u32* d_aux = nullptr;                        // [0]=C0, [1]=jump, [2..33]=ladder : 34 points x 16 words
   u32* d_auxk = nullptr;                       // scalars for the above
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
@@ -198,7 +221,7 @@ void ecl_hip_close(ecl_hip* h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(h->d_tab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
+  (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -396,6 +419,29 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
 }
 
+// ec_gtable_init (lib/ecc.c:880-905) on the device: every slot is an independent double-and-add
+static int ensure_gtable(ecl_hip* h) {
+  if (h->d_gtab) return ECL_OK;
+  const size_t slots = (size_t)GT_WINDOWS * GT_PER;
+  std::vector<u32> ks(slots * 8);
+  for (u32 w = 0; w < GT_WINDOWS; ++w) {
+    u256 base = sc_pow2(w * GT_W), cur = base;
+    for (u32 b = 1; b <= GT_PER; ++b) {
+      words_of(&ks[((size_t)w * GT_PER + b - 1) * 8], cur);
+      cur = sc_add(cur, base);
+    }
+  }
+  u32* d_k = nullptr;
+  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_gtab, slots * 16 * sizeof(u32)));
+  HIPCHK(h, hipMemcpy(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_mul_g, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, h->stream, d_k, h->d_gtab, (u8*)nullptr, (u32)slots);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(d_k));
+  return ECL_OK;
+}
+
 extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
   if (!h || (!scalars && n) || (!out && cap) || !nout) return ECL_E_ARG;
@@ -405,6 +451,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = ensure_found(h, cap ? cap : 1)) != ECL_OK) return rc;
+  if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
   std::vector<u32> ks((size_t)n * 8);
   for (u32 i = 0; i < n; ++i) words_of(&ks[(size_t)i * 8], sc_reduce(u256_from(scalars[i])));
   u32* d_k = nullptr;
@@ -416,10 +463,10 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(u32), h->stream));
   bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
-  dim3 grid((n + 63) / 64), blk(64);
-  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, n, a);
-  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, n, a);
-  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, n, a);
+  dim3 grid((n + 255) / 256), blk(256);
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
   HIPCHK(h, hipGetLastError());
   u32 cnt = 0;
   HIPCHK(h, hipMemcpyAsync(&cnt, h->d_counter, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
