@@ -37,6 +37,9 @@ OPS_PER_KEY = 313 + 350 + 2570
 # peak: one VALU wave-instruction per SIMD per 4 clocks (measured, profiles/ubench_r01.txt): 256 CU x 4 SIMD x 64 lanes
 # x 2.4 GHz / 4 = 39.3 T int32 lane-ops/s
 PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12
+# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 141.9 B + WRITE_SIZE 20.0 B per key:
+# two 64-byte bloom sectors per key + the 40 B / 2 keys prefix-product chain each way). Not the bound: 1.3 TB/s.
+TRAFFIC_BYTES_PER_KEY = 161.9
 
 
 def splitmix_hashes(n, seed):
@@ -93,16 +96,12 @@ def cpu_baseline(words, sample_keys_log2_max=33):
         if not os.path.exists(binary):
             continue
         try:
-            threads = min(cores, 320)
-            rate, secs, _, _ = run(binary, 30, threads)  # calibration: 2^30 keys
+            # the reference stops scaling at a few dozen threads (one mutex-guarded job counter + status line,
+            # main.c:419-431): measured on the 2x EPYC 9575F box 64 Mkeys/s at -t 32/64, 58 at 128, 44 at 256
+            threads = min(cores, 64)
             log2n = 30
-            while log2n < sample_keys_log2_max and (1 << (log2n + 1)) / (rate * 1e6) < 25:
-                log2n += 1
-            if log2n > 30:
-                rate, secs, _, lines = run(binary, log2n, threads)
-            else:
-                _, _, _, lines = run(binary, 30, threads)
-            rate1, _, _, _ = run(binary, 26, 1)
+            rate, secs, _, lines = run(binary, log2n, threads)
+            rate1, _, _, _ = run(binary, 25, 1)
             return {"value": rate, "unit": "Mkeys/s", "cores": threads, "kind": "reference",
                     "sample": f"{os.path.basename(binary)} add -r {RANGE_A:x}:+2^{log2n} same .blf, -t {threads} ({secs:.1f}s); -t 1: {rate1:.2f} Mkeys/s",
                     "single_thread_mkeys": rate1}, (log2n, lines)
@@ -214,7 +213,8 @@ def main():
                    "keys_per_gpu_per_step": nkeys, "parallelism": f"range-sharded x{world}, no collective",
                    "found_per_step": len(ks.found), "planted_found": PLANTED - len(missing)},
         "roofline": {"bound": "valu-int32", "achieved": round(achieved, 3), "peak": round(PEAK_TOPS, 2), "unit": "Tops/s",
-                     "frac": round(achieved / PEAK_TOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_TOPS, 4), "traffic": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY),
+                     "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.txt)",
                      "kernel": "k_add<addr33>", "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch),
                      "ops_per_key": OPS_PER_KEY, "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0},
     }
