@@ -53,12 +53,24 @@ def splitmix_hashes(n, seed):
     return np.ascontiguousarray(w)
 
 
-def build_filter(dev, start, nkeys):
-    """10^7 random entries + PLANTED keys of [start, start+nkeys) -> bloom words resident on `dev`."""
+def build_filter(dev, start, nkeys, filter_n=FILTER_N):
+    """filter_n random entries + PLANTED keys of [start, start+nkeys) -> bloom words resident on `dev`.
+    Above 5*10^7 entries (non-headline experiments, e.g. the ~6 GB filter of configs[2]) the bit array is filled with
+    random words of the design density 0.375 instead of inserting that many hashes."""
     from ecloop_amd.engine import blf_size_words
-    size = blf_size_words(FILTER_N)
-    dev.set_bloom(np.zeros(size, dtype=np.uint64))
-    dev.bloom_insert(splitmix_hashes(FILTER_N, 2025))
+    size = blf_size_words(filter_n)
+    if filter_n > 50_000_000:
+        import torch
+        g = torch.Generator(device="cuda").manual_seed(2025)
+        chunk, parts = 1 << 27, []
+        for at in range(0, size, chunk):
+            m = min(chunk, size - at)
+            a, b, c = (torch.randint(-(1 << 63), (1 << 63) - 1, (m,), dtype=torch.int64, device="cuda", generator=g) for _ in range(3))
+            parts.append((a & (b | c)).cpu().numpy().view(np.uint64))
+        dev.set_bloom(np.concatenate(parts))
+    else:
+        dev.set_bloom(np.zeros(size, dtype=np.uint64))
+        dev.bloom_insert(splitmix_hashes(filter_n, 2025))
     offs = [(nkeys // PLANTED) * i + 12345 * (i + 1) % 4096 for i in range(PLANTED)]
     xs, ys, ok = dev.diag_mulg([start + o for o in offs])
     h33, h65 = dev.diag_hash160(xs, ys)
@@ -128,12 +140,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--keys-log2", type=int, default=32, help="keys per GPU per step (default 2^32 = the named config)")
-    ap.add_argument("--launch-log2", type=int, default=30, help="keys per kernel launch")
+    ap.add_argument("--launch-log2", type=int, default=32, help="largest number of keys given to one device call")
     ap.add_argument("--half-group", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--addr", default="c", choices=["c", "u", "cu"], help="non-headline variants: -a u / -a cu")
     ap.add_argument("--endo", action="store_true", help="non-headline variant: -endo (6 images per key)")
+    ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,11 +166,11 @@ def main():
     start = RANGE_A + rank * nkeys
 
     # --- inputs -> HBM (untimed)
-    headline = args.addr == "c" and not args.endo
+    headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
     ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr,
                    endo=args.endo, verify=True,
                    launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
-    size, planted_offs, planted_h = build_filter(ks.dev, start, nkeys)
+    size, planted_offs, planted_h = build_filter(ks.dev, start, nkeys, args.filter_n)
     words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
 
     def barrier():
@@ -209,7 +222,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"add addr33, 2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}, "
-                               f".blf bloom ({FILTER_N} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
+                               f".blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
                    "keys_per_gpu_per_step": nkeys, "parallelism": f"range-sharded x{world}, no collective",
                    "found_per_step": len(ks.found), "planted_found": PLANTED - len(missing)},
         "roofline": {"bound": "valu-int32", "achieved": round(achieved, 3), "peak": round(PEAK_TOPS, 2), "unit": "Tops/s",

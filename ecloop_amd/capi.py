@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libecloop_hip.so")
+LIB_PATH = os.environ.get("ECLOOP_HIP_LIB") or os.path.join(PKG, "libecloop_hip.so")  # override: A/B builds
 
 ADDR33, ADDR65, ENDO = 1, 2, 4
 E_OVERFLOW = -4
@@ -26,7 +26,7 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_add_range",
-    "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
+    "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
 ]
 
@@ -56,6 +56,7 @@ def load():
     lib.ecl_hip_bloom_insert.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_get_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_set_geometry.argtypes = [P, C.c_uint32, C.c_uint32]
+    lib.ecl_hip_get_geometry.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_reset_timing.argtypes = [P]
     lib.ecl_hip_strerror.argtypes = [C.c_int]
@@ -125,6 +126,12 @@ class Device:
 
     def set_geometry(self, half_group=0, max_lanes=0):
         self._chk(self.lib.ecl_hip_set_geometry(self.h, half_group, max_lanes))
+
+    def geometry(self):
+        """-> (half_group, lanes); one sweep = lanes * 2 * half_group keys"""
+        b, t = C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.ecl_hip_get_geometry(self.h, C.byref(b), C.byref(t)))
+        return b.value, t.value
 
     def add_range(self, start, nkeys, cap=4096):
         """-> (records as numpy structured array, total hit count). Raises on overflow unless total <= cap."""

@@ -142,8 +142,12 @@ __device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 o
   }
 }
 
+// waves per SIMD the register allocator must leave room for (256-thread blocks: blocks per CU = this value)
+#ifndef ECL_ADD_WAVES
+#define ECL_ADD_WAVES 3  /* measured: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33) */
+#endif
 template <bool A33, bool A65, bool ENDO>
-__global__ void __launch_bounds__(256) k_add(const add_args a) {
+__global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
   const u32 g = blockIdx.x * 256u + threadIdx.x;
   const u32 T = a.T, B = a.B;
   if (g >= T) return;

@@ -321,6 +321,16 @@ static int ensure_table(ecl_hip* h) {
   return ECL_OK;
 }
 
+extern "C" int ecl_hip_get_geometry(ecl_hip* h, uint32_t* half_group, uint32_t* lanes) {
+  if (!h) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc = default_lanes(h);
+  if (rc != ECL_OK) return rc;
+  if (half_group) *half_group = h->B;
+  if (lanes) *lanes = h->Tmax;
+  return ECL_OK;
+}
+
 extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
   if (!h || !start || (!out && cap) || !nout) return ECL_E_ARG;
@@ -336,9 +346,11 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   const u32 B = h->B;
   const u64 group = 2ull * B;
   u64 ngroups = (nkeys + group - 1) / group;
-  u32 T = (u32)((ngroups < h->Tmax ? ngroups : h->Tmax) + 255) & ~255u;
+  // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
+  // through a mostly masked last group
+  u32 nb = (u32)((ngroups + h->Tmax - 1) / h->Tmax);
+  u32 T = (u32)(((ngroups + nb - 1) / nb + 255) & ~255ull);
   if (T > h->Tmax) T = h->Tmax;
-  u32 nb = (u32)((ngroups + T - 1) / T);
 
   u256 k0 = sc_reduce(u256_from(start));
   const u256 s = sc_pow2(h->offs);

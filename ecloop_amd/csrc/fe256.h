@@ -37,6 +37,22 @@ struct fe {
 };
 
 #define FE_FN __host__ __device__ __forceinline__
+// Two code-generation pins for the device build (no effect on the value computed):
+//  * FE_PIN64(x): the compiler otherwise re-associates "carry + sum of products" into "sum of products, then add
+//    the carry" (one extra 64-bit add per column); pinning the carry makes it the accumulator the v_mad_u64_u32
+//    chain starts from;
+//  * fe_opaque(c): keeps a multiply by a power-of-two constant (R1 = 2^10) a single v_mad_u64_u32 instead of
+//    mask + move + 64-bit shift + 64-bit add.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FE_PIN64(x) asm("" : "+v"(x))
+FE_FN u32 fe_opaque(u32 c) {
+  asm("" : "+s"(c));
+  return c;
+}
+#else
+#define FE_PIN64(x) ((void)0)
+FE_FN u32 fe_opaque(u32 c) { return c; }
+#endif
 #define FE_M 0x3FFFFFFu
 #define FE_R0 0x3D10u /* 2^260 = R1 * 2^26 + R0 (mod p) */
 #define FE_R1 0x400u
@@ -157,6 +173,7 @@ FE_FN fe fe_sub(const fe& a, const fe& b) { return fe_add(a, fe_neg(b, 1)); }
 FE_FN fe fe_mul(const fe& a, const fe& b) {
   fe r;
   u64 c = 0, d = 0;
+  const u32 R1 = fe_opaque(FE_R1);
 #pragma unroll
   for (int i = 0; i < 10; ++i) d += (u64)a.n[i] * b.n[9 - i];
   const u32 t9 = (u32)d & FE_M;
@@ -164,15 +181,23 @@ FE_FN fe fe_mul(const fe& a, const fe& b) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
 #pragma unroll
-    for (int i = k + 1; i < 10; ++i) d += (u64)a.n[i] * b.n[10 + k - i];
+    for (int i = k + 1; i < 10; ++i) {
+      FE_PIN64(d);
+      d += (u64)a.n[i] * b.n[10 + k - i];
+    }
     const u32 u = (u32)d & FE_M;
     d >>= 26;
 #pragma unroll
-    for (int i = 0; i <= k; ++i) c += (u64)a.n[i] * b.n[k - i];
+    for (int i = 0; i <= k; ++i) {
+      FE_PIN64(c);
+      c += (u64)a.n[i] * b.n[k - i];
+    }
+    FE_PIN64(c);
     c += (u64)u * FE_R0;
     r.n[k] = (u32)c & FE_M;
     c >>= 26;
-    c += (u64)u * FE_R1;
+    FE_PIN64(c);
+    c += (u64)u * R1;
   }
   // column 9: what is left in d sits at 2^(26*19) = 2^(26*9) * 2^260
   c += d * FE_R0 + t9;
@@ -196,11 +221,17 @@ FE_FN fe fe_sqr(const fe& a) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) a2[i] = a.n[i] * 2;
   u64 c = 0, d = 0;
+  const u32 R1 = fe_opaque(FE_R1);
   // column k = sum_{i<j, i+j=k} a_i * 2a_j  (+ a_{k/2}^2)
-#define FE_SQ_COL(acc, k)                                                  \
-  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); ++i)  \
-      acc += (u64)a.n[i] * a2[(k)-i];                                      \
-  if (((k)&1) == 0) acc += (u64)a.n[(k) / 2] * a.n[(k) / 2];
+#define FE_SQ_COL(acc, k)                                                    \
+  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); ++i) {  \
+    FE_PIN64(acc);                                                           \
+    acc += (u64)a.n[i] * a2[(k)-i];                                          \
+  }                                                                          \
+  if (((k)&1) == 0) {                                                        \
+    FE_PIN64(acc);                                                           \
+    acc += (u64)a.n[(k) / 2] * a.n[(k) / 2];                                 \
+  }
   FE_SQ_COL(d, 9)
   const u32 t9 = (u32)d & FE_M;
   d >>= 26;
@@ -210,10 +241,12 @@ FE_FN fe fe_sqr(const fe& a) {
     const u32 u = (u32)d & FE_M;
     d >>= 26;
     FE_SQ_COL(c, k)
+    FE_PIN64(c);
     c += (u64)u * FE_R0;
     r.n[k] = (u32)c & FE_M;
     c >>= 26;
-    c += (u64)u * FE_R1;
+    FE_PIN64(c);
+    c += (u64)u * R1;
   }
 #undef FE_SQ_COL
   c += d * FE_R0 + t9;

@@ -272,9 +272,14 @@ class KeySearch:
 
     def add_keys(self, start, nkeys, cap=4096):
         """hash exactly nkeys keys from `start`, in launches of at most launch_keys keys"""
+        b, lanes = self.dev.geometry()
+        sweep = lanes * 2 * b  # launches that are whole sweeps keep every lane busy and continue without re-init
+        per = max(sweep, self.launch_keys // sweep * sweep)
         done = 0
         while done < nkeys:
-            n = min(self.launch_keys, nkeys - done)
+            n = nkeys - done
+            if n > self.launch_keys:  # what fits one launch goes as one call: the library then sizes the lanes to it
+                n = min(n, per)
             s = (start + done * self.stride) % N
             c = cap
             while True:

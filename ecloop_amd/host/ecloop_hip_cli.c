@@ -349,10 +349,18 @@ typedef struct { ctx_t *ctx; int g; sc start; u64 nkeys; u64 status_total, keys_
 static void *add_worker(void *arg) {
   add_job *j = arg;
   ctx_t *ctx = j->ctx;
-  u32 cap = 4096;
+  u32 cap = 4096, half_group = 0, lanes = 0;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
+  /* launches of whole sweeps (lanes * 2 * half_group keys) keep every lane busy and continue without re-init */
+  u64 per = LAUNCH_KEYS;
+  if (ecl_hip_get_geometry(ctx->dev[j->g], &half_group, &lanes) == ECL_OK && lanes) {
+    u64 sweep = (u64)lanes * 2 * half_group;
+    per = LAUNCH_KEYS / sweep * sweep;
+    if (per < sweep) per = sweep;
+  }
   for (u64 done = 0; done < j->nkeys;) {
-    u64 n = j->nkeys - done < LAUNCH_KEYS ? j->nkeys - done : LAUNCH_KEYS;
+    u64 n = j->nkeys - done;
+    if (n > LAUNCH_KEYS && n > per) n = per; /* what fits one launch goes as one call: the library sizes the lanes to it */
     sc s = sc_add(sc_reduce(j->start), sc_mul(ctx->stride_k, sc_u64(done)));
     u32 cnt = 0;
     int rc;

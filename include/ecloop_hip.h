@@ -91,6 +91,9 @@ int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_
 /* Geometry of the walk: half_group = table points per group (the reference fixes 1024: GROUP_INV_SIZE/2,
    main.c:17), max_lanes = keys walked concurrently.  0 keeps the default.  Results do not depend on either. */
 int ecl_hip_set_geometry(ecl_hip *h, uint32_t half_group, uint32_t max_lanes);
+/* Current geometry.  One "sweep" = lanes * 2 * half_group keys: calls whose nkeys is a multiple of it keep every
+   lane equally busy (no tail) and can be continued by the next contiguous call without re-initialisation. */
+int ecl_hip_get_geometry(ecl_hip *h, uint32_t *half_group, uint32_t *lanes);
 
 /* Measurement: accumulated HIP-event time of the main add kernel since the last reset, and launch count. */
 int ecl_hip_get_timing(ecl_hip *h, double *kernel_ms, uint64_t *launches, uint64_t *keys);
