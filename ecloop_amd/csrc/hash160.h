@@ -17,13 +17,32 @@ H_FN u32 bswap32(u32 x) { return __builtin_bswap32(x); }
 // bitfield select: (m & a) | (~m & b)  -> v_bfi_b32
 H_FN u32 bsel(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
 
+// three-input xor: one v_bitop3_b32 on the device (the compiler prefers two v_xor_b32; ECL_XOR3_BITOP3=0 keeps that)
+#ifndef ECL_XOR3_BITOP3
+#define ECL_XOR3_BITOP3 1
+#endif
+// Boolean functions of three words as ONE v_bitop3_b32 (truth table = f(0xF0, 0xCC, 0xAA)).  Written with the
+// builtin because the compiler otherwise splits Ch / Maj / select into disjoint AND terms that it folds into the
+// additions ((e&f) + (~e&g)), which costs more instructions than it saves.
+#if defined(__HIP_DEVICE_COMPILE__) && ECL_XOR3_BITOP3
+#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x96)
+#define BITSEL(m, a, b) __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA)   /* (m & a) | (~m & b) */
+#define MAJ3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8)     /* majority */
+#define ORN_XOR(x, y, z) __builtin_amdgcn_bitop3_b32(x, y, z, 0x59)  /* (x | ~y) ^ z */
+#else
+#define XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#define BITSEL(m, a, b) (((a) & (m)) | ((b) & ~(m)))
+#define MAJ3(a, b, c) (((a) & (b)) | ((c) & ((a) | (b))))
+#define ORN_XOR(x, y, z) (((x) | ~(y)) ^ (z))
+#endif
+
 // ---------------------------------------------------------------- SHA-256
-#define SHA_S0(x) (rotr32(x, 2) ^ rotr32(x, 13) ^ rotr32(x, 22))
-#define SHA_S1(x) (rotr32(x, 6) ^ rotr32(x, 11) ^ rotr32(x, 25))
-#define SHA_s0(x) (rotr32(x, 7) ^ rotr32(x, 18) ^ ((x) >> 3))
-#define SHA_s1(x) (rotr32(x, 17) ^ rotr32(x, 19) ^ ((x) >> 10))
-#define SHA_CH(e, f, g) bsel(e, f, g)
-#define SHA_MAJ(a, b, c) bsel((a) ^ (b), c, b)
+#define SHA_S0(x) XOR3(rotr32(x, 2), rotr32(x, 13), rotr32(x, 22))
+#define SHA_S1(x) XOR3(rotr32(x, 6), rotr32(x, 11), rotr32(x, 25))
+#define SHA_s0(x) XOR3(rotr32(x, 7), rotr32(x, 18), ((x) >> 3))
+#define SHA_s1(x) XOR3(rotr32(x, 17), rotr32(x, 19), ((x) >> 10))
+#define SHA_CH(e, f, g) BITSEL(e, f, g)
+#define SHA_MAJ(a, b, c) MAJ3(a, b, c)
 
 #define SHA_RND(a, b, c, d, e, f, g, h, k, w)            \
   {                                                      \
@@ -70,11 +89,11 @@ H_FN void sha256_init(u32 st[8]) {
 }
 
 // ---------------------------------------------------------------- RIPEMD-160, one block from the IV
-#define RMD_F1(x, y, z) ((x) ^ (y) ^ (z))
-#define RMD_F2(x, y, z) bsel(x, y, z)
-#define RMD_F3(x, y, z) (((x) | ~(y)) ^ (z))
-#define RMD_F4(x, y, z) bsel(z, x, y)
-#define RMD_F5(x, y, z) ((x) ^ ((y) | ~(z)))
+#define RMD_F1(x, y, z) XOR3(x, y, z)
+#define RMD_F2(x, y, z) BITSEL(x, y, z)
+#define RMD_F3(x, y, z) ORN_XOR(x, y, z)
+#define RMD_F4(x, y, z) BITSEL(z, x, y)
+#define RMD_F5(x, y, z) ORN_XOR(y, z, x)
 #define RMD_STEP(a, b, c, d, e, fn, x, k, s)    \
   {                                             \
     a = rotl32(a + fn(b, c, d) + (x) + (k), s) + e; \
