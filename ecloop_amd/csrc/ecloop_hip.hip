@@ -354,6 +354,17 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
 
   u256 k0 = sc_reduce(u256_from(start));
   const u256 s = sc_pow2(h->offs);
+  {
+    // The walk cannot represent the point at infinity: refuse a scan that contains the scalar 0 (mod n), like the
+    // reference's range check (main.c:687-690).  j0 = offset of that key = -k0 / 2^offs (mod n).
+    u256 j0 = sc_neg(k0);
+    for (u32 i = 0; i < h->offs; ++i) j0 = sc_half(j0);
+    const u64 walked = (u64)nb * T * group;
+    if (!(j0.w[1] | j0.w[2] | j0.w[3]) && j0.w[0] < walked && j0.w[0] < nkeys + group) {
+      h->err = "the scan contains the private key 0 (mod n)";
+      return ECL_E_RANGE;
+    }
+  }
   bool cont = h->walk_valid && h->walk_T == T && u256_eq(h->walk_next, k0);
   if (!cont) {
     // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G

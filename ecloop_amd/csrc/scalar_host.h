@@ -77,3 +77,10 @@ static inline u256 sc_pow2(unsigned e) {  // 2^e mod n, e <= 255
   for (unsigned i = 0; i < e; ++i) r = sc_add(r, r);
   return r;
 }
+// a / 2 mod n (n is odd)
+static inline u256 sc_half(u256 a) {
+  uint64_t carry = 0;
+  if (a.w[0] & 1) carry = u256_add(a, a, SC_N);
+  for (int i = 0; i < 4; ++i) a.w[i] = (a.w[i] >> 1) | ((i < 3 ? a.w[i + 1] : carry) << 63);
+  return a;
+}

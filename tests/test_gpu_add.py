@@ -156,3 +156,18 @@ def test_mul_batch_dump_matches_reference_golden():
                    for r in recs)
     g = G["mul_dump_cu"]
     assert n == g["count"] and orc.digest(lines) == g["sha256_sorted"]
+
+
+def test_scan_through_scalar_zero_is_refused():
+    """the reference cannot walk through the point at infinity either (-r must start above 0x800, main.c:687-690)"""
+    from ecloop_amd import Device, EclError
+    for offs, start in [(0, orc.N - 1000), (0, 0), (7, orc.N - (1000 << 7))]:
+        d = Device(0, ord_offs=offs)
+        try:
+            d.set_bloom(ONES)
+            with pytest.raises(EclError, match="private key 0"):
+                d.add_range(start, 4096, cap=16)
+            recs, n = d.add_range((start + (5000 << offs)) % orc.N, 2048, cap=4096)  # just past it: fine
+            assert n == 2048
+        finally:
+            d.close()
