@@ -147,9 +147,6 @@ __device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 o
 #ifndef ECL_PREFETCH
 #define ECL_PREFETCH 0  /* measured: 0 -> 9.70, 1 -> 9.35 Gkeys/s: register pressure beats latency hiding at 3 waves/SIMD */
 #endif
-#ifndef ECL_RECOMPUTE_NXG
-#define ECL_RECOMPUTE_NXG 0
-#endif
 #ifndef ECL_ADD_WAVES
 #define ECL_ADD_WAVES 3  /* measured: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33) */
 #endif
@@ -200,9 +197,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
       const fe dx = fe_sub(gx, X);
       const fe invk = fe_mul(inv, pre);  // 1 / (Gx_i - X)
       inv = fe_mul(inv, dx);
-#if !ECL_RECOMPUTE_NXG
       const fe nxg = fe_neg(fe_add(X, gx), 2);  // -(X + Gx), magnitude 3
-#endif
       const int nwhich = (k == 1) ? 3 : 2;
 #pragma unroll 1
       for (int which = 0; which < nwhich; ++which) {
@@ -213,9 +208,6 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
           // lambda = (+-Gy - Y) / (Gx - X); x3 = lambda^2 - X - Gx; y3 = lambda (X - x3) - Y   (main.c:379-386)
           fe s = which == 0 ? fe_sub(gy, Y) : fe_neg(fe_add(gy, Y), 2);  // magnitude 3
           fe lam = fe_mul(s, invk);
-#if ECL_RECOMPUTE_NXG
-          const fe nxg = fe_neg(fe_add(X, gx), 2);  // -(X + Gx), magnitude 3; recomputed: 20 cheap ops vs 10 live VGPRs
-#endif
           px = fe_add(fe_sqr(lam), nxg);                                   // magnitude 4
           py = fe_sub(fe_mul(lam, fe_add(X, fe_neg(px, 4))), Y);           // X - px: magnitude 6; py: magnitude 3
           off = which == 0 ? base + B + 1 + i : base + (B - 1 - i);

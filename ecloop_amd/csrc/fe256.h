@@ -123,15 +123,18 @@ FE_FN u32 fe_weak_ge_p(const fe& a) {
 // canonical residue in [0, p)
 FE_FN void fe_normalize(fe& a) {
   fe_normalize_weak(a);
-  u32 x = fe_weak_ge_p(a);
-  a.n[0] += x * 0x3D1u;
-  a.n[1] += x << 6;
+  // the value is in [p, 2p) only with probability ~2^-32 for field-like inputs: keep the final subtraction out of
+  // the straight-line path (a wave takes the branch only if one of its lanes needs it)
+  if (__builtin_expect(fe_weak_ge_p(a) != 0, 0)) {
+    a.n[0] += 0x3D1u;
+    a.n[1] += 1u << 6;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    a.n[i + 1] += a.n[i] >> 26;
-    a.n[i] &= FE_M;
+    for (int i = 0; i < 9; ++i) {
+      a.n[i + 1] += a.n[i] >> 26;
+      a.n[i] &= FE_M;
+    }
+    a.n[9] &= 0x03FFFFFu;  // drops 2^256
   }
-  a.n[9] &= 0x03FFFFFu;  // drops 2^256 when x was set
 }
 // parity of the canonical residue without producing it (p is odd: subtracting it flips the parity)
 FE_FN u32 fe_parity(fe a) {
