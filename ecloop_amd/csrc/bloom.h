@@ -27,13 +27,27 @@ __host__ __device__ inline bloom_t bloom_make(const u64* bits, u64 nwords) {
   b.recip = nwords >= 2 ? (u64)((((unsigned __int128)1) << 64) / nwords) : 0;
   return b;
 }
-// x mod nwords for x < 2^58
+// x mod nwords for x < 2^58.  q = floor(x * recip / 2^64) is floor(x / d) or one less (x < 2^58, so the error of the
+// truncated reciprocal stays below 2^-6): one conditional subtraction finishes it.
 FE_FN u64 bloom_mod(const bloom_t& b, u64 x) {
-  u64 q = mulhi64(x, b.recip);  // q in {floor(x/d) - 1, floor(x/d)}; for d == 1 recip = 0 -> q = 0
+  if (b.nwords < (1ull << 31)) {
+    // filters below 16 GB: the remainder and 2d fit 32 bits, so only the LOW word of q is needed
+    const u32 d = (u32)b.nwords, xl = (u32)x, xh = (u32)(x >> 32), ml = (u32)b.recip, mh = (u32)(b.recip >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 t0 = __umulhi(xl, ml);
+#else
+    const u32 t0 = (u32)(((u64)xl * ml) >> 32);
+#endif
+    const u64 mid = (u64)xl * mh + ((u64)xh * ml + t0);  // mod 2^64: a lost carry only reaches bit 32 of q
+    const u32 q = xh * mh + (u32)(mid >> 32);
+    u32 r = xl - q * d;
+    const u32 r2 = r - d;
+    r = r2 < r ? r2 : r;  // r >= d  <=>  r - d does not wrap
+    return d == 1 ? 0 : r;
+  }
+  u64 q = mulhi64(x, b.recip);
   u64 r = x - q * b.nwords;
   if (r >= b.nwords) r -= b.nwords;
-  if (r >= b.nwords) r -= b.nwords;
-  if (b.nwords == 1) r = 0;
   return r;
 }
 FE_FN u64 bloom_index(const u64 a[5], int probe) {
