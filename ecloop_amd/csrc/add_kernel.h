@@ -33,8 +33,8 @@ struct add_args {
   const u32* __restrict__ tab;  // [B][16]: x[8], y[8] of (i+1)*stride*G, canonical affine
   u32 jump[16];                 // x[8], y[8] of (T*2B*stride)*G
   uint4* __restrict__ cxy;      // lane centres as canonical words, planes {x.lo, x.hi, y.lo, y.hi} x T
-  uint4* __restrict__ scratch;  // prefix products (10x26 limbs 0..7), [(k*2 + half) * T + lane]
-  uint2* __restrict__ scratch2; // prefix products (limbs 8..9), [k * T + lane]
+  uint4* __restrict__ scratch;  // prefix products (9x29 limbs 0..7), [(k*2 + half) * T + lane]
+  u32* __restrict__ scratch2;   // prefix products (limb 8), [k * T + lane]
   bloom_t bloom;
   ecl_found_dev* found;
   u32* counter;
@@ -58,20 +58,19 @@ FE_FN void fe_st_words2(uint4* p, size_t stride, fe a) {  // normalises
   p[0] = make_uint4(w[0], w[1], w[2], w[3]);
   p[stride] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// raw limbs (any magnitude) in planes uint4, uint4, uint2
-FE_FN fe fe_ld_limbs(const uint4* p4, size_t stride4, const uint2* p2) {
+// raw limbs (any magnitude) in planes uint4, uint4, u32
+FE_FN fe fe_ld_limbs(const uint4* p4, size_t stride4, const u32* p1) {
   uint4 a = p4[0], b = p4[stride4];
-  uint2 c = p2[0];
   fe r;
   r.n[0] = a.x, r.n[1] = a.y, r.n[2] = a.z, r.n[3] = a.w;
   r.n[4] = b.x, r.n[5] = b.y, r.n[6] = b.z, r.n[7] = b.w;
-  r.n[8] = c.x, r.n[9] = c.y;
+  r.n[8] = p1[0];
   return r;
 }
-FE_FN void fe_st_limbs(uint4* p4, size_t stride4, uint2* p2, const fe& a) {
+FE_FN void fe_st_limbs(uint4* p4, size_t stride4, u32* p1, const fe& a) {
   p4[0] = make_uint4(a.n[0], a.n[1], a.n[2], a.n[3]);
   p4[stride4] = make_uint4(a.n[4], a.n[5], a.n[6], a.n[7]);
-  p2[0] = make_uint2(a.n[8], a.n[9]);
+  p1[0] = a.n[8];
 }
 // 8 canonical words at p (wave-uniform table / argument data) -> fe
 FE_FN fe fe_ldw(const u32* p) {
@@ -95,14 +94,14 @@ __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32
 
 // hash every selected encoding / endomorphism image of the affine point (x, y) and probe the filter
 // (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327).
-// x, y: magnitude <= 6.
+// x: magnitude <= 4, y: magnitude <= 3.
 template <bool A33, bool A65, bool ENDO>
 __device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 off) {
   u32 xw[3][8], yw[2][8], par = 0;
   if (ENDO) {
     const u32 bw[8] = FE_BETA1_W;
     fe bx = fe_mul(x, fe_from_words(bw));  // magnitude 1
-    fe b2x = fe_neg(fe_add(x, bx), 7);     // beta^2 = -1 - beta
+    fe b2x = fe_neg(fe_add(x, bx), 5);     // beta^2 = -1 - beta; magnitude 6
     fe_normalize(bx);
     fe_normalize(b2x);
     fe_to_words(xw[1], bx);
@@ -160,8 +159,8 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
   fe X = fe_ld_words2(a.cxy + g, plane), Y = fe_ld_words2(a.cxy + 2 * (size_t)T + g, plane);
   const fe Jx = fe_ldw(a.jump), Jy = fe_ldw(a.jump + 8);
   uint4* scr4 = a.scratch + g;
-  uint2* scr2 = a.scratch2 + g;
-  const size_t s4 = 2 * (size_t)T;  // one chain element = two uint4 planes + one uint2 plane
+  u32* scr2 = a.scratch2 + g;
+  const size_t s4 = 2 * (size_t)T;  // one chain element = two uint4 planes + one u32 plane
 
 #pragma unroll 1
   for (u32 b = 0; b < a.nb; ++b) {
@@ -170,6 +169,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
 
     // ---- phase 1: prefix products of e_0 = Jx - X, e_k = Gx_{k-1} - X   (differences have magnitude 3)
     fe acc = fe_sub(Jx, X);
+    fe_normalize_weak(acc);            // magnitude 1: the chain multiplies it by a magnitude-3 difference
     const bool dbl = fe_is_zero(acc);  // C == J: next centre is 2C (C == -J would be the scalar 0: excluded)
     if (dbl) acc = fe_one();
 #pragma unroll 1

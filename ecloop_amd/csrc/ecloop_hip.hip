@@ -95,7 +95,12 @@ __global__ void k_diag_fe(int op, const u32* a, const u32* b, u32* r, u32 n) {
   case 2: z = fe_inv(x); break;
   case 3: z = fe_sub(x, y); break;
   case 4: z = fe_add(x, y); break;
-  default: z = fe_neg(x, 1); break;
+  case 5: z = fe_neg(x, 1); break;
+  // chained operations (one result feeding the next with nothing in between): regression tests for the
+  // dropped-mask miscompile described in fe256.h
+  case 6: z = fe_sqr(fe_sqr(x)); break;
+  case 7: z = fe_mul(fe_mul(x, y), y); break;
+  default: z = fe_mul(fe_sqr(x), x); break;
   }
   fe_normalize(z);
   u32 zw[8];
@@ -151,7 +156,7 @@ struct ecl_hip {
   u32* d_aux = nullptr;                        // [0]=C0, [1]=jump, [2..33]=ladder : 34 points x 16 words
   u32* d_auxk = nullptr;                       // scalars for the above
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
-  uint4* d_scr = nullptr; uint2* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
+  uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
@@ -399,7 +404,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
     h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
     HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
-    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(uint2)));
+    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(u32)));
     h->scr_elems = need;
   }
 
@@ -520,7 +525,7 @@ struct dbuf {
 
 extern "C" int ecl_hip_diag_fe(ecl_hip* h, int op, const uint64_t (*a)[4], const uint64_t (*b)[4], uint64_t (*r)[4],
                                uint32_t n) {
-  if (!h || !a || !r || n == 0 || op < 0 || op > 5) return ECL_E_ARG;
+  if (!h || !a || !r || n == 0 || op < 0 || op > 8) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   size_t bytes = (size_t)n * 32;
   dbuf<u32> da, db, dr;

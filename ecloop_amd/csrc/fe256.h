@@ -2,19 +2,20 @@
 //
 // Replaces the reference's fe_modp_* family (lib/ecc.c:269-540) on the device.
 //
-// Representation: 10 limbs of 26 bits in u32 ("10x26", value = sum n[i] * 2^(26 i)), one lane = one element.
-// Why not the reference's 4 x u64 (or 8 x u32) saturated limbs: on gfx950 v_mad_u64_u32 (32x32+64 -> 64) issues
-// at the same rate as any other VOP3 instruction (profiles/ubench_r01.txt) but it has no carry-in, and a carry
-// chain costs an extra instruction plus wait states per link.  With 26-bit limbs a whole column of the schoolbook
-// product accumulates in one 64-bit register with no carry handling at all (10 products of < 2^60), additions and
-// subtractions are 10 independent 32-bit ops (no carry chain, no reduction), and the reduction by
-// 2^256 = 0x1000003D1 (mod p) is two small multiplies per column.
+// Representation: 9 limbs of 29 bits in u32 ("9x29", value = sum n[i] * 2^(29 i), top limb 24 bits), one lane = one
+// element.  Why not the reference's 4 x u64 (or 8 x u32) saturated limbs: on gfx950 v_mad_u64_u32 (32x32+64 -> 64)
+// issues at the same rate as any other VOP3 instruction (profiles/ubench_r01.txt) but it has no carry-in, and a
+// carry chain costs an extra instruction plus wait states per link.  With unsaturated limbs a whole column of the
+// schoolbook product accumulates in one 64-bit register with no carry handling (9 products of < 2^58 * m1*m2),
+// additions and subtractions are 9 independent 32-bit ops (no carry chain, no reduction), and the reduction by
+// 2^256 = 0x1000003D1 (mod p) is two small multiplies per column.  29 bits is the widest limb that still leaves
+// room for lazy additions: 81 products per multiplication instead of 100 with 26-bit limbs.
 //
-// Magnitude discipline (as in any unsaturated-limb field code): a value has magnitude m if n[i] <= 2m(2^26-1) for
-// i < 9 and n[9] <= 2m(2^22-1).  fe_mul / fe_sqr accept magnitudes <= 8 and return magnitude 1; fe_add adds
-// magnitudes; fe_neg(a, m) returns magnitude m+1.  Only fe_normalize() gives the canonical residue in [0, p), and
-// only canonical values are serialised for hashing, so results are bit-identical to the reference, which hashes
-// canonical values only (DESIGN.md "Canonical form").
+// Magnitude discipline: a value has magnitude m if n[i] <= m * 2^29 (+ a few units) for i < 8 and n[8] <= m * 2^24.
+// fe_mul accepts magnitudes with m1*m2 <= 7 (9 * 7 * 2^58 < 2^64), fe_sqr magnitude <= 2; both return magnitude 1;
+// fe_add adds magnitudes; fe_neg(a, m) returns magnitude m+1; limbs must stay below 2^32, i.e. m <= 7.
+// Only fe_normalize() gives the canonical residue in [0, p), and only canonical values are serialised for hashing,
+// so results are bit-identical to the reference, which hashes canonical values only (DESIGN.md "Canonical form").
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
@@ -32,16 +33,17 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef uint8_t u8;
 
+#define FE_LIMBS 9
 struct fe {
-  u32 n[10];
+  u32 n[FE_LIMBS];
 };
 
 #define FE_FN __host__ __device__ __forceinline__
 // Two code-generation pins for the device build (no effect on the value computed):
 //  * FE_PIN64(x): the compiler otherwise re-associates "carry + sum of products" into "sum of products, then add
-//    the carry" (one extra 64-bit add per column); pinning the carry makes it the accumulator the v_mad_u64_u32
-//    chain starts from;
-//  * fe_opaque(c): keeps a multiply by a power-of-two constant (R1 = 2^10) a single v_mad_u64_u32 instead of
+//    the carry" (one extra 64-bit add per column); pinning every accumulate makes each one a v_mad_u64_u32 that
+//    continues the chain;
+//  * fe_opaque(c): keeps a multiply by a power-of-two constant (R1 = 2^8) a single v_mad_u64_u32 instead of
 //    mask + move + 64-bit shift + 64-bit add.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FE_PIN64(x) asm("" : "+v"(x))
@@ -53,20 +55,32 @@ FE_FN u32 fe_opaque(u32 c) {
 #define FE_PIN64(x) ((void)0)
 FE_FN u32 fe_opaque(u32 c) { return c; }
 #endif
-#define FE_M 0x3FFFFFFu
-#define FE_R0 0x3D10u /* 2^260 = R1 * 2^26 + R0 (mod p) */
-#define FE_R1 0x400u
+// Compiler-bug guard (ROCm 7.2 clang 22, gfx950): when BOTH factors of a 64-bit product are visibly masked to <= 24
+// bits the AMDGPU backend first treats the multiply as a 24-bit one (which lets it drop the masks) and then
+// selects v_mad_u64_u32 on the unmasked registers: the top limb of a field element squared as (c & 0xFFFFFF)^2
+// came out as (low32(c))^2 whenever one multiplication fed another directly.  Reproduced and localised with an
+// instruction-level emulation of the generated code; tests: diag ops 6-8 in tests/test_gpu_primitives.py.
+// FE_HIDE24 makes the masked value opaque so the product is an ordinary 32 x 32 multiply of the masked register.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FE_HIDE24(x) asm("" : "+v"(x))
+#else
+#define FE_HIDE24(x) ((void)0)
+#endif
+#define FE_M 0x1FFFFFFFu
+#define FE_TOP 0x00FFFFFFu /* limb 8: 24 bits */
+#define FE_R0 0x7A20u      /* 2^261 = R1 * 2^29 + R0 (mod p): 32 * (2^32 + 977) */
+#define FE_R1 0x100u
 
-// p in 10x26 limbs
-#define FE_P0 0x3FFFC2Fu
-#define FE_P1 0x3FFFFBFu
-#define FE_PM 0x3FFFFFFu /* limbs 2..8 */
-#define FE_P9 0x03FFFFFu
+// p in 9x29 limbs
+#define FE_P0 0x1FFFFC2Fu
+#define FE_P1 0x1FFFFFF7u
+#define FE_PM 0x1FFFFFFFu /* limbs 2..7 */
+#define FE_P8 0x00FFFFFFu
 
 FE_FN fe fe_zero() {
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) r.n[i] = 0;
+  for (int i = 0; i < FE_LIMBS; ++i) r.n[i] = 0;
   return r;
 }
 FE_FN fe fe_one() {
@@ -79,46 +93,47 @@ FE_FN fe fe_one() {
 FE_FN fe fe_from_words(const u32 w[8]) {
   fe r;
   r.n[0] = w[0] & FE_M;
-  r.n[1] = (w[0] >> 26 | w[1] << 6) & FE_M;
-  r.n[2] = (w[1] >> 20 | w[2] << 12) & FE_M;
-  r.n[3] = (w[2] >> 14 | w[3] << 18) & FE_M;
-  r.n[4] = (w[3] >> 8 | w[4] << 24) & FE_M;
-  r.n[5] = (w[4] >> 2) & FE_M;
-  r.n[6] = (w[4] >> 28 | w[5] << 4) & FE_M;
-  r.n[7] = (w[5] >> 22 | w[6] << 10) & FE_M;
-  r.n[8] = (w[6] >> 16 | w[7] << 16) & FE_M;
-  r.n[9] = w[7] >> 10;
+  r.n[1] = (w[0] >> 29 | w[1] << 3) & FE_M;
+  r.n[2] = (w[1] >> 26 | w[2] << 6) & FE_M;
+  r.n[3] = (w[2] >> 23 | w[3] << 9) & FE_M;
+  r.n[4] = (w[3] >> 20 | w[4] << 12) & FE_M;
+  r.n[5] = (w[4] >> 17 | w[5] << 15) & FE_M;
+  r.n[6] = (w[5] >> 14 | w[6] << 18) & FE_M;
+  r.n[7] = (w[6] >> 11 | w[7] << 21) & FE_M;
+  r.n[8] = w[7] >> 8;
   return r;
 }
 // a must be normalised
 FE_FN void fe_to_words(u32 w[8], const fe& a) {
-  w[0] = a.n[0] | a.n[1] << 26;
-  w[1] = a.n[1] >> 6 | a.n[2] << 20;
-  w[2] = a.n[2] >> 12 | a.n[3] << 14;
-  w[3] = a.n[3] >> 18 | a.n[4] << 8;
-  w[4] = a.n[4] >> 24 | a.n[5] << 2 | a.n[6] << 28;
-  w[5] = a.n[6] >> 4 | a.n[7] << 22;
-  w[6] = a.n[7] >> 10 | a.n[8] << 16;
-  w[7] = a.n[8] >> 16 | a.n[9] << 10;
+  w[0] = a.n[0] | a.n[1] << 29;
+  w[1] = a.n[1] >> 3 | a.n[2] << 26;
+  w[2] = a.n[2] >> 6 | a.n[3] << 23;
+  w[3] = a.n[3] >> 9 | a.n[4] << 20;
+  w[4] = a.n[4] >> 12 | a.n[5] << 17;
+  w[5] = a.n[5] >> 15 | a.n[6] << 14;
+  w[6] = a.n[6] >> 18 | a.n[7] << 11;
+  w[7] = a.n[7] >> 21 | a.n[8] << 8;
 }
 
-// magnitude 1 result: the overflow above 2^256 folded in first, then one carry pass
+// magnitude 1 result: the overflow above 2^256 folded in first (2^256 = 2^32 + 977: limb 1 gets x * 8), then one
+// carry pass
 FE_FN void fe_normalize_weak(fe& a) {
-  u32 x = a.n[9] >> 22;
-  a.n[9] &= 0x03FFFFFu;
+  u32 x = a.n[8] >> 24;
+  a.n[8] &= FE_TOP;
   a.n[0] += x * 0x3D1u;
-  a.n[1] += x << 6;
+  a.n[1] += x << 3;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    a.n[i + 1] += a.n[i] >> 26;
+  for (int i = 0; i < 8; ++i) {
+    a.n[i + 1] += a.n[i] >> 29;
     a.n[i] &= FE_M;
   }
+  FE_HIDE24(a.n[8]);
 }
-// 1 if a weakly normalised value (it is < 2p; n[9] may carry bit 22) is >= p
+// 1 if a weakly normalised value (it is < 2p; n[8] may carry bit 24) is >= p
 FE_FN u32 fe_weak_ge_p(const fe& a) {
-  u32 m = a.n[2] & a.n[3] & a.n[4] & a.n[5] & a.n[6] & a.n[7] & a.n[8];
-  return (a.n[9] >> 22) |
-         ((a.n[9] == 0x03FFFFFu) & (m == FE_M) & ((a.n[1] + 0x40u + ((a.n[0] + 0x3D1u) >> 26)) > FE_M));
+  u32 m = a.n[2] & a.n[3] & a.n[4] & a.n[5] & a.n[6] & a.n[7];
+  return (a.n[8] >> 24) |
+         ((a.n[8] == FE_TOP) & (m == FE_M) & ((a.n[1] + 8u + ((a.n[0] + 0x3D1u) >> 29)) > FE_M));
 }
 // canonical residue in [0, p)
 FE_FN void fe_normalize(fe& a) {
@@ -127,13 +142,14 @@ FE_FN void fe_normalize(fe& a) {
   // the straight-line path (a wave takes the branch only if one of its lanes needs it)
   if (__builtin_expect(fe_weak_ge_p(a) != 0, 0)) {
     a.n[0] += 0x3D1u;
-    a.n[1] += 1u << 6;
+    a.n[1] += 8u;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      a.n[i + 1] += a.n[i] >> 26;
+    for (int i = 0; i < 8; ++i) {
+      a.n[i + 1] += a.n[i] >> 29;
       a.n[i] &= FE_M;
     }
-    a.n[9] &= 0x03FFFFFu;  // drops 2^256
+    a.n[8] &= FE_TOP;  // drops 2^256
+    FE_HIDE24(a.n[8]);
   }
 }
 // parity of the canonical residue without producing it (p is odd: subtracting it flips the parity)
@@ -141,55 +157,76 @@ FE_FN u32 fe_parity(fe a) {
   fe_normalize_weak(a);
   return (a.n[0] ^ fe_weak_ge_p(a)) & 1u;
 }
-// is the value 0 mod p?  (any magnitude <= 8)
+// is the value 0 mod p?  (any magnitude <= 7)
 FE_FN bool fe_is_zero(fe a) {
   fe_normalize(a);
   u32 o = 0;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) o |= a.n[i];
+  for (int i = 0; i < FE_LIMBS; ++i) o |= a.n[i];
   return o == 0;
 }
 
 FE_FN fe fe_add(const fe& a, const fe& b) {  // magnitude ma + mb
   fe r;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) r.n[i] = a.n[i] + b.n[i];
+  for (int i = 0; i < FE_LIMBS; ++i) r.n[i] = a.n[i] + b.n[i];
   return r;
 }
-// -a for a of magnitude <= m; result magnitude m + 1   (2(m+1)p - a, limb-wise, never underflows)
+// -a for a of magnitude <= m; result magnitude m + 1   ((m+1) p - a, limb-wise, never underflows)
 FE_FN fe fe_neg(const fe& a, u32 m) {
   fe r;
-  const u32 k = 2 * (m + 1);
+  const u32 k = m + 1;
   r.n[0] = FE_P0 * k - a.n[0];
   r.n[1] = FE_P1 * k - a.n[1];
 #pragma unroll
-  for (int i = 2; i < 9; ++i) r.n[i] = FE_PM * k - a.n[i];
-  r.n[9] = FE_P9 * k - a.n[9];
+  for (int i = 2; i < 8; ++i) r.n[i] = FE_PM * k - a.n[i];
+  r.n[8] = FE_P8 * k - a.n[8];
   return r;
 }
 // a - b for b of magnitude 1; result magnitude ma + 2
 FE_FN fe fe_sub(const fe& a, const fe& b) { return fe_add(a, fe_neg(b, 1)); }
 
-// lib/ecc.c:307-347. Inputs of magnitude <= 8, output magnitude 1.
-// Columns 9..18 stream through d (their 26-bit digits u are folded down by 2^260 = R1*2^26 + R0), columns 0..8
+// shared tail of fe_mul / fe_sqr: column 8, then the fold of everything above 2^256
+FE_FN void fe_mul_tail(fe& r, u64 c, u64 d, u32 t8) {
+  // what is left in d sits at 2^(29*17) = 2^(29*8) * 2^261
+  c += d * FE_R0 + t8;
+  r.n[8] = (u32)c & FE_TOP;
+  FE_HIDE24(r.n[8]);
+  c >>= 24;
+  c += d * ((u64)FE_R1 << 5);
+  // c * 2^256 = c * (2^32 + 977): limbs 0 and 1, then a short carry
+  d = c * (FE_R0 >> 5) + r.n[0];
+  r.n[0] = (u32)d & FE_M;
+  d >>= 29;
+  d += c * (FE_R1 >> 5) + r.n[1];
+  r.n[1] = (u32)d & FE_M;
+  d >>= 29;
+  r.n[2] += (u32)d;
+}
+
+// lib/ecc.c:307-347. Inputs with m1*m2 <= 7, output magnitude 1.
+// Columns 8..16 stream through d (their 29-bit digits u are folded down by 2^261 = R1*2^29 + R0), columns 0..7
 // stream through c: every column is carried exactly once.
 FE_FN fe fe_mul(const fe& a, const fe& b) {
   fe r;
   u64 c = 0, d = 0;
   const u32 R1 = fe_opaque(FE_R1);
 #pragma unroll
-  for (int i = 0; i < 10; ++i) d += (u64)a.n[i] * b.n[9 - i];
-  const u32 t9 = (u32)d & FE_M;
-  d >>= 26;
+  for (int i = 0; i < 9; ++i) {
+    FE_PIN64(d);
+    d += (u64)a.n[i] * b.n[8 - i];
+  }
+  const u32 t8 = (u32)d & FE_M;
+  d >>= 29;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < 8; ++k) {
 #pragma unroll
-    for (int i = k + 1; i < 10; ++i) {
+    for (int i = k + 1; i < 9; ++i) {
       FE_PIN64(d);
-      d += (u64)a.n[i] * b.n[10 + k - i];
+      d += (u64)a.n[i] * b.n[9 + k - i];
     }
     const u32 u = (u32)d & FE_M;
-    d >>= 26;
+    d >>= 29;
 #pragma unroll
     for (int i = 0; i <= k; ++i) {
       FE_PIN64(c);
@@ -198,36 +235,25 @@ FE_FN fe fe_mul(const fe& a, const fe& b) {
     FE_PIN64(c);
     c += (u64)u * FE_R0;
     r.n[k] = (u32)c & FE_M;
-    c >>= 26;
+    c >>= 29;
     FE_PIN64(c);
     c += (u64)u * R1;
   }
-  // column 9: what is left in d sits at 2^(26*19) = 2^(26*9) * 2^260
-  c += d * FE_R0 + t9;
-  r.n[9] = (u32)c & (FE_M >> 4);
-  c >>= 22;
-  c += d * ((u64)FE_R1 << 4);
-  // c * 2^256 = c * (2^32 + 977): limbs 0 and 1, then a short carry
-  d = c * (FE_R0 >> 4) + r.n[0];
-  r.n[0] = (u32)d & FE_M;
-  d >>= 26;
-  d += c * (FE_R1 >> 4) + r.n[1];
-  r.n[1] = (u32)d & FE_M;
-  d >>= 26;
-  r.n[2] += (u32)d;
+  fe_mul_tail(r, c, d, t8);
   return r;
 }
 // lib/ecc.c:349-444. Same schedule with the symmetric products taken once against the doubled operand.
+// Input magnitude <= 2 (the doubled limbs must stay below 2^32 and 9 * 4 * 2^58 below 2^64).
 FE_FN fe fe_sqr(const fe& a) {
   fe r;
-  u32 a2[10];
+  u32 a2[9];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) a2[i] = a.n[i] * 2;
+  for (int i = 0; i < 9; ++i) a2[i] = a.n[i] * 2;
   u64 c = 0, d = 0;
   const u32 R1 = fe_opaque(FE_R1);
   // column k = sum_{i<j, i+j=k} a_i * 2a_j  (+ a_{k/2}^2)
 #define FE_SQ_COL(acc, k)                                                    \
-  _Pragma("unroll") for (int i = ((k) > 9 ? (k)-9 : 0); 2 * i < (k); ++i) {  \
+  _Pragma("unroll") for (int i = ((k) > 8 ? (k)-8 : 0); 2 * i < (k); ++i) {  \
     FE_PIN64(acc);                                                           \
     acc += (u64)a.n[i] * a2[(k)-i];                                          \
   }                                                                          \
@@ -235,34 +261,24 @@ FE_FN fe fe_sqr(const fe& a) {
     FE_PIN64(acc);                                                           \
     acc += (u64)a.n[(k) / 2] * a.n[(k) / 2];                                 \
   }
-  FE_SQ_COL(d, 9)
-  const u32 t9 = (u32)d & FE_M;
-  d >>= 26;
+  FE_SQ_COL(d, 8)
+  const u32 t8 = (u32)d & FE_M;
+  d >>= 29;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    FE_SQ_COL(d, 10 + k)
+  for (int k = 0; k < 8; ++k) {
+    FE_SQ_COL(d, 9 + k)
     const u32 u = (u32)d & FE_M;
-    d >>= 26;
+    d >>= 29;
     FE_SQ_COL(c, k)
     FE_PIN64(c);
     c += (u64)u * FE_R0;
     r.n[k] = (u32)c & FE_M;
-    c >>= 26;
+    c >>= 29;
     FE_PIN64(c);
     c += (u64)u * R1;
   }
 #undef FE_SQ_COL
-  c += d * FE_R0 + t9;
-  r.n[9] = (u32)c & (FE_M >> 4);
-  c >>= 22;
-  c += d * ((u64)FE_R1 << 4);
-  d = c * (FE_R0 >> 4) + r.n[0];
-  r.n[0] = (u32)d & FE_M;
-  d >>= 26;
-  d += c * (FE_R1 >> 4) + r.n[1];
-  r.n[1] = (u32)d & FE_M;
-  d >>= 26;
-  r.n[2] += (u32)d;
+  fe_mul_tail(r, c, d, t8);
   return r;
 }
 
@@ -272,7 +288,7 @@ __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {
   return a;
 }
 // a^(p-2): the 255 S + 15 M addition chain of lib/ecc.c:463-520 (x2,x3,x6,x9,x11,x22,x44,x88,x176,x220,x223).
-// Input magnitude <= 8, output magnitude 1.
+// Input magnitude <= 2, output magnitude 1.
 __host__ __device__ __noinline__ inline fe fe_inv(const fe& a) {
   fe x2 = fe_mul(fe_sqr(a), a);
   fe x3 = fe_mul(fe_sqr(x2), a);

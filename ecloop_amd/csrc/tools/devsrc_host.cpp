@@ -30,8 +30,14 @@ void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
   case 3: z = fe_sub(x, y); break;
   case 4: z = fe_add(x, y); break;
   case 5: z = fe_neg(x, 1); break;
-  case 6: z = fe_mul(fe_add(fe_add(x, x), fe_add(x, x)), fe_sub(fe_add(y, y), x)); break;  // magnitudes 4 and 4
-  case 7: z = fe_sqr(fe_add(fe_add(fe_add(x, x), fe_add(x, x)), fe_add(fe_add(y, y), fe_add(y, y)))); break;  // magnitude 8
+  case 6: z = fe_mul(fe_add(fe_add(x, x), x), fe_add(y, y)); break;  // magnitudes 3 x 2
+  case 7: z = fe_sqr(fe_add(x, y)); break;                           // magnitude 2
+  case 8: {                                                          // magnitudes 1 x 7: the limit
+    fe y7 = fe_neg(fe_neg(fe_neg(fe_neg(fe_neg(fe_neg(y, 1), 2), 3), 4), 5), 6);
+    z = fe_mul(x, y7);
+    break;
+  }
+  case 9: z = fe_mul(fe_neg(fe_add(x, x), 2), fe_add(y, y)); break;  // magnitudes 3 x 2 with a negated operand
   default: z = fe_zero();
   }
   st(r, z);

@@ -32,16 +32,18 @@ def test_field(D):
         return orc.val(r)
 
     edge = [0, 1, 2, P - 1, P - 2, 0x1000003D1, 1 << 255, P - 0x1000003D1, (1 << 32) - 1, (1 << 224) - 1,
-            P - (1 << 26), (1 << 26) - 1, (1 << 234) - 1, P - 1 - (1 << 234)]
+            P - (1 << 29), (1 << 29) - 1, (1 << 232) - 1, P - 1 - (1 << 232), (1 << 256) - (1 << 232) - 1 - 0x1000003D1]
     vals = edge + [rnd.randrange(P) for _ in range(200)]
     for a in vals:
         for b in vals[:24]:
             assert op(0, a, b) == a * b % P
             assert op(3, a, b) == (a - b) % P
             assert op(4, a, b) == (a + b) % P
-            # unnormalised (lazy) operands: magnitudes 4 x 4 into mul, 8 into sqr, parity of a magnitude-4 value
-            assert op(6, a, b) == (4 * a * (2 * b - a)) % P
-            assert op(7, a, b) == ((4 * a + 4 * b) ** 2) % P
+            # unnormalised (lazy) operands at the documented magnitude limits, parity of a magnitude-4 value
+            assert op(6, a, b) == (3 * a * 2 * b) % P
+            assert op(7, a, b) == ((a + b) ** 2) % P
+            assert op(8, a, b) == (a * b) % P  # six negations: magnitude 7, value +b
+            assert op(9, a, b) == (-2 * a * 2 * b) % P
             assert D.dh_parity(orc.fe(a), orc.fe(b)) == ((2 * a - b) % P) & 1
         assert op(1, a) == a * a % P
         assert op(5, a) == (-a) % P

@@ -31,6 +31,10 @@ def test_field_ops(dev):
     assert dev.diag_fe(3, a, b) == [(x - y) % P for x, y in zip(a, b)]
     assert dev.diag_fe(4, a, b) == [(x + y) % P for x, y in zip(a, b)]
     assert dev.diag_fe(5, a) == [(-x) % P for x in a]
+    # chained operations: a result feeding the next multiplication directly (compiler-bug regression, see fe256.h)
+    assert dev.diag_fe(6, a) == [pow(x, 4, P) for x in a]
+    assert dev.diag_fe(7, a, b) == [x * y % P * y % P for x, y in zip(a, b)]
+    assert dev.diag_fe(8, a) == [pow(x, 3, P) for x in a]
     nz = [x for x in a if x][:1500]
     assert dev.diag_fe(2, nz) == [pow(x, P - 2, P) for x in nz]
 
