@@ -26,7 +26,7 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_add_range",
-    "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_strerror",
+    "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
 ]
 
@@ -59,6 +59,7 @@ def load():
     lib.ecl_hip_get_geometry.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_reset_timing.argtypes = [P]
+    lib.ecl_hip_selftest.argtypes = [P]
     lib.ecl_hip_strerror.argtypes = [C.c_int]
     lib.ecl_hip_strerror.restype = C.c_char_p
     lib.ecl_hip_last_error.argtypes = [P]
@@ -149,6 +150,9 @@ class Device:
         rc = self.lib.ecl_hip_mul_batch(self.h, k.ctypes.data, len(k), out.ctypes.data, cap, C.byref(n))
         self._chk(rc, allow=(E_OVERFLOW,))
         return out[: min(n.value, cap)], n.value
+
+    def selftest(self):
+        self._chk(self.lib.ecl_hip_selftest(self.h))
 
     def timing(self):
         ms, launches, keys = C.c_double(), C.c_uint64(), C.c_uint64()

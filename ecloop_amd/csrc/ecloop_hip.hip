@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -200,6 +201,7 @@ const char* ecl_hip_strerror(int code) {
   case ECL_E_OVERFLOW: return "more hits than the output buffer holds";
   case ECL_E_NOBLOOM: return "no bloom filter set";
   case ECL_E_RANGE: return "range touches scalar 0 (mod n)";
+  case ECL_E_SELFTEST: return "device self-test failed";
   default: return "unknown error";
   }
 }
@@ -219,6 +221,8 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_counter, sizeof(u32)));
+  const char* skip = getenv("ECL_HIP_SKIP_SELFTEST");
+  if (!(skip && skip[0] == '1')) return ecl_hip_selftest(h);
   return ECL_OK;
 }
 
@@ -628,5 +632,77 @@ extern "C" int ecl_hip_diag_bloom(ecl_hip* h, const uint32_t (*h160)[5], uint8_t
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ self-test
+
+extern "C" int ecl_hip_selftest(ecl_hip* h) {
+  if (!h) return ECL_E_ARG;
+  // (1) known answers: hash160 of k*G for k = 1, 2, 0xdc2a04 (compressed, uncompressed), public vectors
+  static const uint64_t KS[3][4] = {{1, 0, 0, 0}, {2, 0, 0, 0}, {0xdc2a04, 0, 0, 0}};
+  static const uint32_t KAT33[3][5] = {{0x751e76e8u, 0x199196d4u, 0x54941c45u, 0xd1b3a323u, 0xf1433bd6u},
+                                       {112186475u, 3455918831u, 2494304810u, 2703172626u, 1151565516u},
+                                       {156887041u, 569600746u, 330545875u, 1640062380u, 639147567u}};
+  static const uint32_t KAT65[3][5] = {{0x91b24bf9u, 0xf5288532u, 0x960ac687u, 0xabb03512u, 0x7b1d28a5u},
+                                       {3603490856u, 3253510587u, 2691031480u, 1042137763u, 1849195074u},
+                                       {3514751675u, 162192179u, 1444810732u, 2475417333u, 3394525481u}};
+  uint64_t x[3][4], y[3][4];
+  uint8_t ok[3];
+  uint32_t h33[3][5], h65[3][5];
+  int rc = ecl_hip_diag_mulg(h, KS, x, y, ok, 3);
+  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(h, x, y, h33, h65, 3);
+  if (rc != ECL_OK) return rc;
+  if (memcmp(h33, KAT33, sizeof KAT33) != 0 || memcmp(h65, KAT65, sizeof KAT65) != 0 || !(ok[0] && ok[1] && ok[2])) {
+    h->err = "known-answer test of k*G -> hash160 failed";
+    return ECL_E_SELFTEST;
+  }
+  // (2) the walk kernel against the double-and-add kernel: 4096 consecutive keys through an all-ones filter
+  const u32 N = 4096, saveB = h->B, saveT = h->Tmax;
+  u64* save_bloom = h->d_bloom;
+  const u64 save_words = h->bloom_words;
+  std::vector<u64> ones(64, ~0ull);
+  h->d_bloom = nullptr, h->bloom_words = 0;
+  h->B = 16, h->Tmax = 256;
+  const uint64_t start[4] = {0x0123456789abcdefull, 0x1f, 0, 0};
+  const u32 per_key = ((h->flags & ECL_ADDR33) ? 1 : 0) + ((h->flags & ECL_ADDR65) ? 1 : 0);
+  const u32 cap = N * per_key * ((h->flags & ECL_ENDO) ? 6 : 1);
+  std::vector<ecl_found> recs(cap);
+  u32 n = 0;
+  rc = ecl_hip_set_bloom(h, ones.data(), ones.size());
+  if (rc == ECL_OK) rc = ecl_hip_add_range(h, start, N, recs.data(), cap, &n);
+  std::vector<uint64_t> ks((size_t)N * 4), xs((size_t)N * 4), ys((size_t)N * 4);
+  std::vector<uint32_t> r33((size_t)N * 5), r65((size_t)N * 5);
+  const u256 s = sc_pow2(h->offs);
+  u256 cur = sc_reduce(u256_from(start));
+  for (u32 i = 0; i < N; ++i) {
+    memcpy(&ks[(size_t)i * 4], cur.w, 32);
+    cur = sc_add(cur, s);
+  }
+  if (rc == ECL_OK) rc = ecl_hip_diag_mulg(h, (const uint64_t(*)[4])ks.data(), (uint64_t(*)[4])xs.data(), (uint64_t(*)[4])ys.data(), nullptr, N);
+  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(h, (const uint64_t(*)[4])xs.data(), (const uint64_t(*)[4])ys.data(),
+                                              (uint32_t(*)[5])r33.data(), (uint32_t(*)[5])r65.data(), N);
+  // restore the caller's state whatever happened
+  if (h->d_bloom) (void)hipFree(h->d_bloom);
+  h->d_bloom = save_bloom, h->bloom_words = save_words;
+  h->B = saveB, h->Tmax = saveT;
+  if (h->d_tab) (void)hipFree(h->d_tab);
+  h->d_tab = nullptr, h->tab_B = 0, h->walk_valid = false;
+  h->kernel_ms = 0, h->launches = 0, h->keys = 0;
+  if (rc != ECL_OK) return rc;
+  u32 seen = 0;
+  bool good = n == cap;
+  for (u32 i = 0; i < n && good; ++i) {
+    const ecl_found& f = recs[i];
+    if (f.key_offset >= N) { good = false; break; }
+    if (f.endo != 0) continue;  // the endomorphism images are covered by the parity tests; here: the walk itself
+    const uint32_t* want = f.compressed ? &r33[f.key_offset * 5] : &r65[f.key_offset * 5];
+    good = memcmp(f.h160, want, 20) == 0;
+    ++seen;
+  }
+  if (!good || seen != N * per_key) {
+    h->err = "walk kernel disagrees with the double-and-add kernel";
+    return ECL_E_SELFTEST;
+  }
   return ECL_OK;
 }

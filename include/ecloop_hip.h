@@ -47,6 +47,7 @@ typedef struct ecl_hip ecl_hip; /* opaque per-device context */
 #define ECL_E_OVERFLOW (-4) /* more hits than `cap`: *nout = total hits, only `cap` records were written */
 #define ECL_E_NOBLOOM (-5)  /* add/mul called before ecl_hip_set_bloom */
 #define ECL_E_RANGE (-6)    /* range touches the scalar 0 (mod n) neighbourhood the method cannot represent */
+#define ECL_E_SELFTEST (-7) /* the device code failed its known-answer / cross-path self-test (miscompile, bad GPU) */
 
 /* One bloom-filter hit.  key_offset counts keys from the `start` scalar of the call in units of the stride:
    privkey = start + key_offset * 2^ord_offs (mod n), then the endo map of calc_priv (main.c:267-276):
@@ -98,6 +99,11 @@ int ecl_hip_get_geometry(ecl_hip *h, uint32_t *half_group, uint32_t *lanes);
 /* Measurement: accumulated HIP-event time of the main add kernel since the last reset, and launch count. */
 int ecl_hip_get_timing(ecl_hip *h, double *kernel_ms, uint64_t *launches, uint64_t *keys);
 int ecl_hip_reset_timing(ecl_hip *h);
+
+/* Known-answer test of the device code (hash160 of 1*G, 2*G, 0xdc2a04*G, both encodings, via the double-and-add
+   kernel) and a cross-check of the walk kernel against it over 4096 consecutive keys.  ecl_hip_open() runs it
+   (a few ms) unless the environment has ECL_HIP_SKIP_SELFTEST=1; a failure makes open return ECL_E_SELFTEST. */
+int ecl_hip_selftest(ecl_hip *h);
 
 const char *ecl_hip_strerror(int code);
 const char *ecl_hip_last_error(const ecl_hip *h);

@@ -75,3 +75,11 @@ def test_bloom_probe(dev, nwords, mode):
     exp = np.array([orc.lib().orc_blf_has(p2, orc.C.c_uint64(len(w2)), orc.H160(*[int(v) for v in h])) for h in hs], dtype=np.uint8)
     assert hit[:200].all()
     assert (hit == exp).all()
+
+
+def test_selftest_passes_and_leaves_state_alone(dev):
+    """ecl_hip_open already ran it; run it again with a filter set and make sure the filter survives"""
+    w = synth_bloom_words(4099, 5, "a|b")
+    dev.set_bloom(w)
+    dev.selftest()
+    assert (dev.get_bloom(len(w)) == w).all()
