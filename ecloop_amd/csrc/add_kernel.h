@@ -92,11 +92,72 @@ __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32
   }
 }
 
+// ---- two-stage filter test -----------------------------------------------------------------------------------
+// Stage 1 (two probes) runs on every hash.  Its survivors (14 % at the .blf design density) are not finished on
+// the spot - a handful of live lanes would drag all 64 lanes of the wave through up to 18 more dependent probes
+// (measured: 6 % of the kernel) - but parked in a per-wave ring in LDS; whenever 64 have gathered, each lane takes
+// one and the wave runs stage 2 densely.  Wave-private: no barrier, no atomics; records: key offset, hash160, tag.
+#define ECL_Q_SLOTS 128u
+struct cand_queue {
+  u32* mem;    // this wave's slice of LDS: 8 fields x ECL_Q_SLOTS words, field-major (conflict-free for lane-contiguous slots)
+  u32 head;    // wave-uniform
+  u32 count;   // wave-uniform, < 64 between calls
+};
+
+__device__ __forceinline__ void cand_confirm(const add_args& a, const cand_queue& q, u32 slot, bool live) {
+  if (!live) return;
+  u32 h[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) h[i] = q.mem[(2 + i) * ECL_Q_SLOTS + slot];
+  if (bloom_stage2(a.bloom, h)) {
+    const u64 off = (u64)q.mem[slot] | (u64)q.mem[ECL_Q_SLOTS + slot] << 32;
+    const u32 tag = q.mem[7 * ECL_Q_SLOTS + slot];
+    found_push(a, off, h, tag & 0xff, (tag >> 8) & 1);
+  }
+}
+__device__ __forceinline__ void cand_drain64(const add_args& a, cand_queue& q) {
+  const u32 lane = threadIdx.x & 63u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  cand_confirm(a, q, (q.head + lane) & (ECL_Q_SLOTS - 1), true);
+  q.head = (q.head + 64) & (ECL_Q_SLOTS - 1);
+  q.count -= 64;
+}
+__device__ __forceinline__ void cand_flush(const add_args& a, cand_queue& q) {  // end of the kernel: the remainder
+  const u32 lane = threadIdx.x & 63u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  cand_confirm(a, q, (q.head + lane) & (ECL_Q_SLOTS - 1), lane < q.count);
+  q.count = 0;
+}
+// Filter test of one hash; q == nullptr: no queue (`mul` kernel), everything in place.  With a queue the call must
+// be reached by ALL lanes of the wave together (head / count are wave-uniform state): lanes whose key is outside
+// the range come along with live = false.
+__device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, bool live, u64 off, const u32 h[5], u32 endo,
+                                             u32 compressed) {
+  const bool pass = live && bloom_stage1(a.bloom, h);
+  if (!q) {
+    if (pass && bloom_stage2(a.bloom, h)) found_push(a, off, h, endo, compressed);
+    return;
+  }
+  const u64 m = __builtin_amdgcn_ballot_w64(pass);
+  if (m == 0) return;
+  if (pass) {
+    const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+    const u32 slot = (q->head + q->count + below) & (ECL_Q_SLOTS - 1);
+    q->mem[slot] = (u32)off;
+    q->mem[ECL_Q_SLOTS + slot] = (u32)(off >> 32);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) q->mem[(2 + i) * ECL_Q_SLOTS + slot] = h[i];
+    q->mem[7 * ECL_Q_SLOTS + slot] = endo | (compressed << 8);
+  }
+  q->count += (u32)__builtin_popcountll(m);
+  if (q->count >= 64) cand_drain64(a, *q);
+}
+
 // hash every selected encoding / endomorphism image of the affine point (x, y) and probe the filter
 // (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327).
 // x: magnitude <= 4, y: magnitude <= 3.
 template <bool A33, bool A65, bool ENDO>
-__device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 off) {
+__device__ __forceinline__ void check_point(const add_args& a, cand_queue* q, bool live, fe x, fe y, u64 off) {
   u32 xw[3][8], yw[2][8], par = 0;
   if (ENDO) {
     const u32 bw[8] = FE_BETA1_W;
@@ -129,14 +190,14 @@ __device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 o
     for (int i = 0; i < 8; ++i) xs[i] = ENDO ? (e < 2 ? xw[0][i] : (e < 4 ? xw[1][i] : xw[2][i])) : xw[0][i];
     if (A33) {
       hash160_33(h, xs, (par ^ (u32)e) & 1u);  // parity(-y) = !parity(y): p is odd, y != 0
-      if (bloom_has(a.bloom, h)) found_push(a, off, h, e, 1);
+      filter_check(a, q, live, off, h, e, 1);
     }
     if (A65) {
       u32 ys[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) ys[i] = (ENDO && (e & 1)) ? yw[1][i] : yw[0][i];
       hash160_65(h, xs, ys);
-      if (bloom_has(a.bloom, h)) found_push(a, off, h, e, 0);
+      filter_check(a, q, live, off, h, e, 0);
     }
   }
 }
@@ -151,6 +212,9 @@ __device__ __forceinline__ void check_point(const add_args& a, fe x, fe y, u64 o
 #endif
 template <bool A33, bool A65, bool ENDO>
 __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
+  __shared__ u32 q_mem[4][8 * ECL_Q_SLOTS];  // one candidate ring per wave
+  cand_queue q;
+  q.mem = q_mem[threadIdx.x >> 6], q.head = 0, q.count = 0;
   const u32 g = blockIdx.x * 256u + threadIdx.x;
   const u32 T = a.T, B = a.B;
   if (g >= T) return;
@@ -165,7 +229,9 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
 #pragma unroll 1
   for (u32 b = 0; b < a.nb; ++b) {
     const u64 base = ((u64)b * T + g) * (2ull * B);
-    if (base >= a.nkeys) break;  // groups only grow: nothing left for this lane
+    // groups only grow: a wave leaves when none of its lanes has keys left (wave-uniform control flow keeps the
+    // candidate queue state uniform; the lane count is sized to the range, so idle lanes are rare)
+    if (__builtin_amdgcn_ballot_w64(base < a.nkeys) == 0) break;
 
     // ---- phase 1: prefix products of e_0 = Jx - X, e_k = Gx_{k-1} - X   (differences have magnitude 3)
     fe acc = fe_sub(Jx, X);
@@ -203,7 +269,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
       for (int which = 0; which < nwhich; ++which) {
         fe px, py;
         u64 off;
-        bool valid = true;
+        bool valid = true;  // wave-uniform
         if (which < 2) {
           // lambda = (+-Gy - Y) / (Gx - X); x3 = lambda^2 - X - Gx; y3 = lambda (X - x3) - Y   (main.c:379-386)
           fe s = which == 0 ? fe_sub(gy, Y) : fe_neg(fe_add(gy, Y), 2);  // magnitude 3
@@ -215,7 +281,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
         } else {
           px = X, py = Y, off = base + B;
         }
-        if (valid && off < a.nkeys) check_point<A33, A65, ENDO>(a, px, py, off);
+        if (valid) check_point<A33, A65, ENDO>(a, &q, off < a.nkeys, px, py, off);
       }
 #if ECL_PREFETCH
       pre = nxt;
@@ -235,6 +301,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
     fe_normalize_weak(Yn);
     X = Xn, Y = Yn;
   }
+  cand_flush(a, q);
   fe_st_words2(a.cxy + g, plane, X);
   fe_st_words2(a.cxy + 2 * (size_t)T + g, plane, Y);
 }

@@ -57,18 +57,28 @@ FE_FN u64 bloom_index(const u64 a[5], int probe) {
 }
 FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (b.bits[bloom_mod(b, idx >> 6)] >> (idx & 63)) & 1; }
 
-// lib/utils.c:308-326. The first two probes are issued together (independent loads), the remaining 18 only
-// by lanes that passed both, one at a time with early-out.
-FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) {
-  u64 a[5];
+// lib/utils.c:308-326 in two stages.  Stage 1: probes 0 and 1, issued together (independent loads); at the `.blf`
+// design density 0.375 it rejects 86 % of the hashes.  Stage 2: the remaining 18 probes, one at a time with the
+// reference's early-out.  bloom_has() = both stages; the add kernel queues the survivors of stage 1 per wave and runs
+// stage 2 on 64 of them at a time (add_kernel.h: cand_queue), because inside the hot loop a few surviving lanes would
+// keep the whole wave iterating.
+FE_FN void bloom_words_of(u64 a[5], const u32 h[5]) {
   a[0] = (u64)h[0] << 32 | h[1];
   a[1] = (u64)h[2] << 32 | h[3];
   a[2] = (u64)h[4] << 32 | h[0];
   a[3] = (u64)h[1] << 32 | h[2];
   a[4] = (u64)h[3] << 32 | h[4];
+}
+FE_FN bool bloom_stage1(const bloom_t& b, const u32 h[5]) {
+  u64 a[5];
+  bloom_words_of(a, h);
   bool p0 = bloom_bit(b, bloom_index(a, 0));
   bool p1 = bloom_bit(b, bloom_index(a, 1));
-  if (!(p0 && p1)) return false;
+  return p0 && p1;
+}
+FE_FN bool bloom_stage2(const bloom_t& b, const u32 h[5]) {
+  u64 a[5];
+  bloom_words_of(a, h);
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     const int S = s == 0 ? 24 : s == 1 ? 28 : s == 2 ? 36 : 40;
@@ -81,7 +91,7 @@ FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) {
   }
   return true;
 }
-
+FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) { return bloom_stage1(b, h) && bloom_stage2(b, h); }
 #if defined(__HIPCC__)
 // lib/utils.c:290-306 (blf_add) for one hash: 20 atomic ORs
 __device__ __forceinline__ void bloom_add(const bloom_t& b, u64* bits, const u32 h[5]) {

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
   }
   fe x, y;
   if (!jac_to_affine(x, y, acc)) return;
-  check_point<A33, A65, false>(a, x, y, (u64)i);
+  check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)i);
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
