@@ -80,3 +80,21 @@ def test_default_geometry_large_scan_false_positives_match_oracle():
     rc, out, n, _, hashed = orc.add_range(orc.OrcFilter(bloom_words=words), start, start + nkeys, verify=False, threads=64, cap=1 << 16)
     assert rc == 0 and hashed == nkeys
     assert got == sorted(orc.found_lines(out, n)) and len(got) > 1000
+
+
+def test_cu_endo_large_scan_false_positives_match_oracle():
+    """BASELINE configs[2] in small: `-a cu -endo` (12 hashes per key) over 2^20 keys at the default geometry, every
+    bloom hit equal to the oracle's (private keys through the endomorphism maps included)."""
+    from ecloop_amd.engine import Filter, KeySearch
+    words = synth_bloom_words(77777, seed=9, mode="a|(b&c)")
+    start, nkeys = 0x200000000, 1 << 20
+    ks = KeySearch(Filter(words), device=0, a33=True, a65=True, endo=True, verify=True)
+    try:
+        ks.add_keys(start, nkeys, cap=1 << 16)
+        got = sorted(r.line() for r in ks.found)
+    finally:
+        ks.close()
+    rc, out, n, _, hashed = orc.add_range(orc.OrcFilter(bloom_words=words), start, start + nkeys, a65=True, endo=True, verify=False,
+                                          threads=64, cap=1 << 16)
+    assert rc == 0 and hashed == nkeys
+    assert got == sorted(orc.found_lines(out, n)) and len(got) > 500
