@@ -30,7 +30,7 @@ struct ecl_found_dev {
 };
 
 struct add_args {
-  const u32* __restrict__ tab;  // [B][16]: x[8], y[8] of (i+1)*stride*G, canonical affine
+  const u32* __restrict__ tab;  // [B][ECL_TAB_STRIDE]: limbs x[9], y[9] of (i+1)*stride*G (normalised 9x29), 2 words pad
   u32 jump[16];                 // x[8], y[8] of (T*2B*stride)*G
   uint4* __restrict__ cxy;      // lane centres as canonical words, planes {x.lo, x.hi, y.lo, y.hi} x T
   uint4* __restrict__ scratch;  // prefix products (9x29 limbs 0..7), [(k*2 + half) * T + lane]
@@ -72,7 +72,19 @@ FE_FN void fe_st_limbs(uint4* p4, size_t stride4, u32* p1, const fe& a) {
   p4[stride4] = make_uint4(a.n[4], a.n[5], a.n[6], a.n[7]);
   p1[0] = a.n[8];
 }
-// 8 canonical words at p (wave-uniform table / argument data) -> fe
+// Table entries are read through the constant address space: the address is wave-uniform (kernel argument + loop
+// counter), so these become scalar loads (s_load_dwordx*) into SGPRs and everything computed from them alone
+// (negation, X-independent sums) runs on the scalar unit; the limbs are stored ready-made so there is nothing to
+// convert.  The table is written by an earlier kernel and never by this one.
+#define ECL_TAB_STRIDE 20u
+typedef const __attribute__((address_space(4))) u32* ctab_ptr;
+__device__ __forceinline__ fe fe_ld_tab(ctab_ptr p) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < FE_LIMBS; ++i) r.n[i] = p[i];
+  return r;
+}
+// 8 canonical words at p (argument data) -> fe
 FE_FN fe fe_ldw(const u32* p) {
   u32 w[8];
 #pragma unroll
@@ -222,6 +234,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
   // centre (X, Y): canonical in HBM, magnitude 1 in registers
   fe X = fe_ld_words2(a.cxy + g, plane), Y = fe_ld_words2(a.cxy + 2 * (size_t)T + g, plane);
   const fe Jx = fe_ldw(a.jump), Jy = fe_ldw(a.jump + 8);
+  const ctab_ptr tab = (ctab_ptr)(uintptr_t)a.tab;
   uint4* scr4 = a.scratch + g;
   u32* scr2 = a.scratch2 + g;
   const size_t s4 = 2 * (size_t)T;  // one chain element = two uint4 planes + one u32 plane
@@ -241,7 +254,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
 #pragma unroll 1
     for (u32 k = 1; k <= B; ++k) {
       fe_st_limbs(scr4 + (size_t)(k - 1) * s4, plane, scr2 + (size_t)(k - 1) * plane, acc);
-      fe dx = fe_sub(fe_ldw(a.tab + (size_t)(k - 1) * 16), X);
+      fe dx = fe_sub(fe_ld_tab(tab + (size_t)(k - 1) * ECL_TAB_STRIDE), X);
       acc = fe_mul(acc, dx);
     }
     // ---- phase 2: one inversion for the whole chain
@@ -259,7 +272,7 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
 #else
       const fe pre = fe_ld_limbs(scr4 + (size_t)i * s4, plane, scr2 + (size_t)i * plane);
 #endif
-      const fe gx = fe_ldw(a.tab + (size_t)i * 16), gy = fe_ldw(a.tab + (size_t)i * 16 + 8);
+      const fe gx = fe_ld_tab(tab + (size_t)i * ECL_TAB_STRIDE), gy = fe_ld_tab(tab + (size_t)i * ECL_TAB_STRIDE + FE_LIMBS);
       const fe dx = fe_sub(gx, X);
       const fe invk = fe_mul(inv, pre);  // 1 / (Gx_i - X)
       inv = fe_mul(inv, dx);

@@ -32,6 +32,16 @@ __global__ void __launch_bounds__(64) k_mul_g(const u32* __restrict__ k, u32* __
   if (ok) ok[i] = (u8)fin;
 }
 
+// canonical words {x[8], y[8]} -> the add kernel's table format {limbs x[9], limbs y[9], pad}
+__global__ void k_tab_to_limbs(const u32* __restrict__ words, u32* __restrict__ tab, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x = fe_ldw(words + (size_t)i * 16), y = fe_ldw(words + (size_t)i * 16 + 8);
+#pragma unroll
+  for (int q = 0; q < FE_LIMBS; ++q) tab[(size_t)i * ECL_TAB_STRIDE + q] = x.n[q], tab[(size_t)i * ECL_TAB_STRIDE + FE_LIMBS + q] = y.n[q];
+  tab[(size_t)i * ECL_TAB_STRIDE + 18] = 0, tab[(size_t)i * ECL_TAB_STRIDE + 19] = 0;
+}
+
 // lane centres C_g = C_0 + g*D from the ladder {2^j * D}: at most 32 mixed additions + one inversion per lane
 __global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0, const u32* __restrict__ ladder,
                                                        uint4* __restrict__ cxy, u32 T) {
@@ -318,14 +328,18 @@ static int ensure_table(ecl_hip* h) {
     words_of(&ks[(size_t)i * 8], cur);
     cur = sc_add(cur, s);
   }
-  u32* d_k = nullptr;
+  u32 *d_k = nullptr, *d_w = nullptr;
   HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&h->d_tab, (size_t)B * 16 * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&d_w, (size_t)B * 16 * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_tab, (size_t)B * ECL_TAB_STRIDE * sizeof(u32)));
   HIPCHK(h, hipMemcpyAsync(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_mul_g, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_k, h->d_tab, (u8*)nullptr, B);
+  hipLaunchKernelGGL(k_mul_g, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_k, d_w, (u8*)nullptr, B);
+  HIPCHK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_tab_to_limbs, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_w, h->d_tab, B);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipFree(d_k));
+  HIPCHK(h, hipFree(d_w));
   h->tab_B = B;
   return ECL_OK;
 }
