@@ -506,31 +506,127 @@ static void mul_flush(ctx_t *ctx, u64 (*ks)[4], u32 n) {
   free(buf);
   ctx_update(ctx, n);
 }
-/* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches */
+/* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches.
+   The reference parses in its worker threads (main.c:503-527); here the GPU does the curve work, so the text side
+   must keep up with ~75 M scalars/s: stdin is read in 64 MB chunks cut at a line end, every chunk is counted and
+   parsed by a pool of threads (two passes: lines per slice, then parse into the final slots, order preserved),
+   and the device call for chunk i runs while chunk i+1 is being parsed.
+   Difference kept small on purpose: a line longer than 1024 characters is one line here (the reference's fgets
+   splits it, main.c:552). */
+static signed char HEXVAL[256];
+static void hexval_init(void) {
+  memset(HEXVAL, -1, sizeof HEXVAL);
+  for (int c = '0'; c <= '9'; ++c) HEXVAL[c] = (signed char)(c - '0');
+  for (int c = 'a'; c <= 'f'; ++c) HEXVAL[c] = (signed char)(c - 'a' + 10), HEXVAL[c - 32] = (signed char)(c - 'a' + 10);
+}
+static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
+  sc k = {{0, 0, 0, 0}};
+  if (!ctx->raw_text) { /* fe_modn_from_hex: right to left, non-hex skipped, 64 digits at most */
+    int cnt = 0;
+    for (size_t i = len; i-- > 0 && cnt < 64;) {
+      int v = HEXVAL[(u8)p[i]];
+      if (v < 0) continue;
+      k.w[cnt >> 4] |= (u64)v << ((cnt & 15) * 4);
+      cnt++;
+    }
+    return sc_reduce(k);
+  }
+  u32 st[8];
+  sha256_host(st, (const u8 *)p, len);
+  k.w[0] = (u64)st[6] << 32 | st[7], k.w[1] = (u64)st[4] << 32 | st[5];
+  k.w[2] = (u64)st[2] << 32 | st[3], k.w[3] = (u64)st[0] << 32 | st[1];
+  return k;
+}
+typedef struct {
+  const ctx_t *ctx;
+  const char *buf;
+  size_t beg, end; /* slice [beg, end): starts at a line start, ends after a '\n' (or at the chunk end) */
+  u64 (*ks)[4];    /* NULL: count only */
+  size_t count, out;
+} parse_slice;
+static void *parse_worker(void *arg) {
+  parse_slice *s = arg;
+  size_t n = 0, at = s->beg;
+  while (at < s->end) {
+    const char *nl = memchr(s->buf + at, '\n', s->end - at);
+    size_t stop = nl ? (size_t)(nl - s->buf) : s->end, len = stop - at;
+    if (len && s->buf[at + len - 1] == '\r') len--;
+    if (len) {
+      if (s->ks) {
+        sc k = line_to_scalar(s->ctx, s->buf + at, len);
+        memcpy(s->ks[s->out + n], k.w, 32);
+      }
+      n++;
+    }
+    at = stop + 1;
+  }
+  s->count = n;
+  return NULL;
+}
+typedef struct { ctx_t *ctx; u64 (*ks)[4]; size_t n; } mul_gpu_job;
+static void *mul_gpu_worker(void *arg) {
+  mul_gpu_job *j = arg;
+  const size_t STEP = 1u << 22; /* scalars per device call */
+  for (size_t at = 0; at < j->n; at += STEP) mul_flush(j->ctx, j->ks + at, (u32)(j->n - at < STEP ? j->n - at : STEP));
+  return NULL;
+}
 static void cmd_mul(ctx_t *ctx) {
   ctx->ts_started = tsnow();
-  const u32 BATCH = 1u << 16;
-  u64(*ks)[4] = malloc((size_t)BATCH * 32);
-  u32 n = 0;
-  char line[MAX_LINE_SIZE];
-  while (fgets(line, sizeof line, stdin)) {
-    size_t len = strlen(line);
-    if (len && line[len - 1] == '\n') line[--len] = 0;
-    if (len && line[len - 1] == '\r') line[--len] = 0;
-    if (!len) continue;
-    sc k;
-    if (!ctx->raw_text) k = sc_from_hex(line);
-    else {
-      u32 st[8];
-      sha256_host(st, (const u8 *)line, len);
-      k.w[0] = (u64)st[6] << 32 | st[7], k.w[1] = (u64)st[4] << 32 | st[5];
-      k.w[2] = (u64)st[2] << 32 | st[3], k.w[3] = (u64)st[0] << 32 | st[1];
+  hexval_init();
+  const size_t CHUNK = 64u << 20;
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  int P = (int)(ncpu < 1 ? 1 : ncpu > 32 ? 32 : ncpu);
+  char *buf = malloc(CHUNK + MAX_LINE_SIZE * 64);
+  size_t have = 0;
+  u64(*ks[2])[4] = {NULL, NULL};
+  size_t cap[2] = {0, 0};
+  pthread_t gpu_thread;
+  mul_gpu_job gjob;
+  bool gpu_busy = false;
+  int cur = 0;
+  bool eof = false;
+  while (!eof || have) {
+    size_t got = eof ? 0 : fread(buf + have, 1, CHUNK - have, stdin);
+    if (got == 0) eof = true;
+    have += got;
+    if (!have) break;
+    /* cut at the last line end; at EOF take everything */
+    size_t end = have;
+    if (!eof) {
+      while (end > 0 && buf[end - 1] != '\n') end--;
+      if (end == 0) { /* one line longer than the chunk: grow is not worth it, treat what we have as a line */
+        end = have;
+      }
     }
-    memcpy(ks[n++], k.w, 32);
-    if (n == BATCH) mul_flush(ctx, ks, n), n = 0;
+    /* slices at line boundaries */
+    parse_slice sl[32];
+    pthread_t th[32];
+    int ns = 0;
+    size_t at = 0;
+    for (int i = 0; i < P && at < end; ++i) {
+      size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
+      if (stop <= at) stop = at + 1;
+      while (stop < end && buf[stop - 1] != '\n') stop++;
+      sl[ns] = (parse_slice){ctx, buf, at, stop, NULL, 0, 0};
+      at = stop, ns++;
+    }
+    for (int i = 0; i < ns; ++i) pthread_create(&th[i], NULL, parse_worker, &sl[i]);
+    size_t total = 0;
+    for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL), sl[i].out = total, total += sl[i].count;
+    if (total > cap[cur]) free(ks[cur]), ks[cur] = malloc(total * 32), cap[cur] = total;
+    for (int i = 0; i < ns; ++i) sl[i].ks = ks[cur], pthread_create(&th[i], NULL, parse_worker, &sl[i]);
+    for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL);
+    /* hand the parsed chunk to the GPU thread, keep parsing the next one meanwhile */
+    if (gpu_busy) pthread_join(gpu_thread, NULL);
+    gjob = (mul_gpu_job){ctx, ks[cur], total};
+    pthread_create(&gpu_thread, NULL, mul_gpu_worker, &gjob);
+    gpu_busy = true;
+    cur ^= 1;
+    memmove(buf, buf + end, have - end);
+    have -= end;
   }
-  mul_flush(ctx, ks, n);
-  free(ks);
+  if (gpu_busy) pthread_join(gpu_thread, NULL);
+  free(buf), free(ks[0]), free(ks[1]);
   ctx_finish(ctx);
 }
 
