@@ -78,7 +78,8 @@ class Filter:
     def __init__(self, words, hashes=None):
         self.words = np.ascontiguousarray(words, dtype=np.uint64)
         self.hashes = hashes  # sorted unique (count x 5) uint32, or None
-        self._set = None if hashes is None else {tuple(int(v) for v in r) for r in hashes}
+        # big-endian bytes of the 5 words compare like compare_160 (lib/addr.c:18-26): binary search on 20-byte keys
+        self._keys = None if hashes is None else np.ascontiguousarray(np.asarray(hashes, dtype=">u4")).view("S20").reshape(-1)
 
     @property
     def count(self):
@@ -86,7 +87,11 @@ class Filter:
 
     def confirm(self, h160):
         """second stage of ctx_check_hash (main.c:212-216): exact membership in list mode, always true in bloom mode"""
-        return True if self._set is None else tuple(int(v) for v in h160) in self._set
+        if self._keys is None:
+            return True
+        key = np.asarray([int(v) for v in h160], dtype=">u4").tobytes()
+        i = int(np.searchsorted(self._keys, np.bytes_(key)))
+        return i < len(self._keys) and self._keys[i].ljust(20, b"\0") == key
 
 
 def parse_hash_list(path):

@@ -103,6 +103,17 @@ def test_load_filter_list_and_blf(tmp_path):
         load_filter(str(tmp_path / "bad.blf"))
 
 
+def test_list_confirm_binary_search_edge_cases():
+    from ecloop_amd.engine import Filter
+    hs = np.unique(np.array([[1, 2, 3, 4, 0], [1, 2, 3, 4, 1], [0, 0, 0, 0, 0], [0xFFFFFFFF] * 5, [1, 2, 3, 0x04000000, 0],
+                             [0, 0, 0, 0, 0x100]], dtype=np.uint32), axis=0)
+    f = Filter(np.zeros(4, dtype=np.uint64), hs)
+    for h in hs:
+        assert f.confirm(h)
+    for h in ([1, 2, 3, 4, 2], [0, 0, 0, 0, 1], [1, 2, 3, 5, 0], [0xFFFFFFFF] * 4 + [0xFFFFFFFE], [1, 2, 3, 4, 0x01000000]):
+        assert not f.confirm(h)
+
+
 def test_blf_gen_bytes_on_host(tmp_path):
     """host-side blf_add reproduces the reference's blf-gen file byte for byte"""
     import hashlib
