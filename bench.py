@@ -154,10 +154,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # test hook (not used by the driver): ECL_BENCH_SHARE_GPU=1 lets several ranks run on one GPU with the gloo
+    # backend, to exercise the N>1 code path on a single-GPU box
+    share = os.environ.get("ECL_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
 
@@ -193,7 +201,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -204,7 +212,7 @@ def main():
         raise SystemExit(f"[bench] rank {rank}: planted keys not found: {missing}")
     kernel_ms, launches, kkeys = ks.dev.timing()
 
-    ok_flag = torch.tensor([1], device="cuda") if dist is not None else None
+    ok_flag = torch.tensor([1], device="cpu" if share else "cuda") if dist is not None else None
     if dist is not None:
         dist.all_reduce(ok_flag)
     if rank != 0:
