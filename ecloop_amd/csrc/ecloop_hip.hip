@@ -312,7 +312,19 @@ static int default_lanes(ecl_hip* h) {
   int occ = 0;
   HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)pick_add_kernel(h->flags), 256, 0));
   if (occ < 1) occ = 1;
-  h->Tmax = (u32)p.multiProcessorCount * (u32)occ * 256u;
+  const u32 resident = (u32)p.multiProcessorCount * (u32)occ * 256u;
+  // Oversubscribe: with exactly the resident number of lanes every wave of the chip is in the same phase at the same
+  // time (prefix products, then the inversion chain, then the hash-heavy walk back); with several times more blocks
+  // than slots the dispatcher staggers them and the phases overlap.  Measured on addr33: 196608 lanes (resident)
+  // 10.9 Gkeys/s, 786432 11.5, 1048576 12.0, 2097152 12.1.  The chains cost lanes * B * 36 bytes of HBM
+  // (2^20 lanes, B = 1024: 38 GB), so the factor is cut back if memory is short.
+  u64 lanes = 1ull << 20;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    while (lanes > resident && lanes * h->B * 36ull > free_b / 3) lanes /= 2;
+  }
+  if (lanes < resident) lanes = resident;
+  h->Tmax = (u32)((lanes + 255) & ~255ull);
   return ECL_OK;
 }
 
