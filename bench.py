@@ -37,9 +37,9 @@ OPS_PER_KEY = 313 + 350 + 2570
 # peak: one VALU wave-instruction per SIMD per 4 clocks (measured, profiles/ubench_r01.txt): 256 CU x 4 SIMD x 64 lanes
 # x 2.4 GHz / 4 = 39.3 T int32 lane-ops/s
 PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12
-# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 140.9 B + WRITE_SIZE 18.0 B per key:
-# two 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.74 TB/s.
-TRAFFIC_BYTES_PER_KEY = 158.9
+# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 141.0 B + WRITE_SIZE 18.1 B per key:
+# two 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.9 TB/s.
+TRAFFIC_BYTES_PER_KEY = 159.1
 
 
 def splitmix_hashes(n, seed):
