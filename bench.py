@@ -39,7 +39,7 @@ OPS_PER_KEY = 313 + 350 + 2570
 PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12
 # HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 141.0 B + WRITE_SIZE 18.1 B per key:
 # two 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.9 TB/s.
-TRAFFIC_BYTES_PER_KEY = 159.1
+TRAFFIC_BYTES_PER_KEY = 121.9
 
 
 def splitmix_hashes(n, seed):

@@ -105,9 +105,9 @@ __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32
 }
 
 // ---- two-stage filter test -----------------------------------------------------------------------------------
-// Stage 1 (two probes) runs on every hash.  Its survivors (14 % at the .blf design density) are not finished on
+// Stage 1 (bloom.h: one probe) runs on every hash.  Its survivors (37 % at the .blf design density) are not finished on
 // the spot - a handful of live lanes would drag all 64 lanes of the wave through up to 18 more dependent probes
-// (measured: 6 % of the kernel) - but parked in a per-wave ring in LDS; whenever 64 have gathered, each lane takes
+// (measured: 6 % of the kernel with 14 % survivors) - but parked in a per-wave ring in LDS; whenever 64 have gathered, each lane takes
 // one and the wave runs stage 2 densely.  Wave-private: no barrier, no atomics; records: key offset, hash160, tag.
 #define ECL_Q_SLOTS 128u
 struct cand_queue {
@@ -143,13 +143,7 @@ __device__ __forceinline__ void cand_flush(const add_args& a, cand_queue& q) {  
 // Filter test of one hash; q == nullptr: no queue (`mul` kernel), everything in place.  With a queue the call must
 // be reached by ALL lanes of the wave together (head / count are wave-uniform state): lanes whose key is outside
 // the range come along with live = false.
-__device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, bool live, u64 off, const u32 h[5], u32 endo,
-                                             u32 compressed) {
-  const bool pass = live && bloom_stage1(a.bloom, h);
-  if (!q) {
-    if (pass && bloom_stage2(a.bloom, h)) found_push(a, off, h, endo, compressed);
-    return;
-  }
+__device__ __forceinline__ void cand_push(const add_args& a, cand_queue* q, bool pass, u64 off, const u32 h[5], u32 tag) {
   const u64 m = __builtin_amdgcn_ballot_w64(pass);
   if (m == 0) return;
   if (pass) {
@@ -159,10 +153,21 @@ __device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, b
     q->mem[ECL_Q_SLOTS + slot] = (u32)(off >> 32);
 #pragma unroll
     for (int i = 0; i < 5; ++i) q->mem[(2 + i) * ECL_Q_SLOTS + slot] = h[i];
-    q->mem[7 * ECL_Q_SLOTS + slot] = endo | (compressed << 8);
+    q->mem[7 * ECL_Q_SLOTS + slot] = tag;
   }
   q->count += (u32)__builtin_popcountll(m);
   if (q->count >= 64) cand_drain64(a, *q);
+}
+// (Deferring the stage-1 test by one hash - loads in flight under the next hash160 - was measured: no gain, the
+// other waves of the SIMD already cover the probe latency.)
+__device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, bool live, u64 off, const u32 h[5], u32 endo,
+                                             u32 compressed) {
+  const bool pass = live && bloom_stage1(a.bloom, h);
+  if (!q) {
+    if (pass && bloom_stage2(a.bloom, h)) found_push(a, off, h, endo, compressed);
+    return;
+  }
+  cand_push(a, q, pass, off, h, endo | (compressed << 8));
 }
 
 // hash every selected encoding / endomorphism image of the affine point (x, y) and probe the filter

@@ -57,9 +57,11 @@ FE_FN u64 bloom_index(const u64 a[5], int probe) {
 }
 FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (b.bits[bloom_mod(b, idx >> 6)] >> (idx & 63)) & 1; }
 
-// lib/utils.c:308-326 in two stages.  Stage 1: probes 0 and 1, issued together (independent loads); at the `.blf`
-// design density 0.375 it rejects 86 % of the hashes.  Stage 2: the remaining 18 probes, one at a time with the
-// reference's early-out.  bloom_has() = both stages; the add kernel queues the survivors of stage 1 per wave and runs
+// lib/utils.c:308-326 in two stages.  Stage 1: probe 0 alone (at the `.blf` design density 0.375 it rejects 62 % of
+// the hashes; ECL_STAGE1_PROBES = 2 issues probes 0 and 1 together and rejects 86 %).  Stage 2: the remaining
+// probes, one at a time with the reference's early-out.  Measured on MI355X, addr33 over 2^32 keys: 54 MB filter
+// 11.95 vs 11.95 Gkeys/s (1 vs 2 probes), 5.9 GB filter 11.09 vs 10.69 - a multi-GB filter is bound by the number
+// of random HBM sectors touched, and one probe first touches 1.59 per hash instead of 2.22.  bloom_has() = both stages; the add kernel queues the survivors of stage 1 per wave and runs
 // stage 2 on 64 of them at a time (add_kernel.h: cand_queue), because inside the hot loop a few surviving lanes would
 // keep the whole wave iterating.
 FE_FN void bloom_words_of(u64 a[5], const u32 h[5]) {
@@ -69,12 +71,19 @@ FE_FN void bloom_words_of(u64 a[5], const u32 h[5]) {
   a[3] = (u64)h[1] << 32 | h[2];
   a[4] = (u64)h[3] << 32 | h[4];
 }
+#ifndef ECL_STAGE1_PROBES
+#define ECL_STAGE1_PROBES 1
+#endif
 FE_FN bool bloom_stage1(const bloom_t& b, const u32 h[5]) {
   u64 a[5];
   bloom_words_of(a, h);
   bool p0 = bloom_bit(b, bloom_index(a, 0));
+#if ECL_STAGE1_PROBES == 2
   bool p1 = bloom_bit(b, bloom_index(a, 1));
   return p0 && p1;
+#else
+  return p0;
+#endif
 }
 FE_FN bool bloom_stage2(const bloom_t& b, const u32 h[5]) {
   u64 a[5];
@@ -84,7 +93,7 @@ FE_FN bool bloom_stage2(const bloom_t& b, const u32 h[5]) {
     const int S = s == 0 ? 24 : s == 1 ? 28 : s == 2 ? 36 : 40;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {  // unrolled: a[] must stay in registers (no runtime indexing)
-      if (s == 0 && j < 2) continue;
+      if (s == 0 && j < ECL_STAGE1_PROBES) continue;
       u64 idx = a[j] << S | a[(j + 1) % 5] >> S;
       if (!bloom_bit(b, idx)) return false;
     }
