@@ -22,7 +22,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/select.h>
 #include <sys/time.h>
+#include <termios.h>
 #include <unistd.h>
 
 #include "ecloop_hip.h"
@@ -232,6 +235,8 @@ typedef struct ctx_t {
   bool a33, a65, endo, quiet, use_color, raw_text, has_seed, finished;
   FILE *outfile;
   u64 ts_started, ts_updated, ts_printed;
+  volatile bool paused; /* 'p' / 'r' on the terminal (main.c:41-46,874-888) */
+  u64 ts_paused_at, paused_time;
   u32 *list; /* sorted unique hashes (5 words each) or NULL in bloom-only mode (main.c:49-51) */
   u64 list_count;
   blf_t blf;
@@ -278,12 +283,13 @@ static void load_filter(ctx_t *ctx, const char *path) {
 
 /* status line, main.c:134-144 */
 static void ctx_print_unlocked(ctx_t *ctx) {
-  int64_t eff = (int64_t)(ctx->ts_updated - ctx->ts_started);
+  const char *msg = ctx->finished ? "" : (ctx->paused ? " ('r' \xe2\x80\x93 resume)" : " ('p' \xe2\x80\x93 pause)");
+  int64_t eff = (int64_t)(ctx->ts_updated - ctx->ts_started) - (int64_t)ctx->paused_time;
   double dt = (eff < 1 ? 1 : eff) / 1000.0;
   double it = ctx->k_checked / dt / 1000000;
   term_clear_line();
-  fprintf(stderr, "%.2fs ~ %.2f Mkeys/s ~ %'llu / %'llu%c", dt, it, (unsigned long long)ctx->k_found,
-          (unsigned long long)ctx->k_checked, ctx->finished ? '\n' : '\r');
+  fprintf(stderr, "%.2fs ~ %.2f Mkeys/s ~ %'llu / %'llu%s%c", dt, it, (unsigned long long)ctx->k_found,
+          (unsigned long long)ctx->k_checked, msg, ctx->finished ? '\n' : '\r');
   fflush(stderr);
 }
 static void ctx_update(ctx_t *ctx, u64 k) { /* main.c:158-172 */
@@ -292,6 +298,7 @@ static void ctx_update(ctx_t *ctx, u64 k) { /* main.c:158-172 */
   ctx->k_checked += k, ctx->ts_updated = ts;
   if (ts - ctx->ts_printed >= 100) ctx->ts_printed = ts, ctx_print_unlocked(ctx);
   pthread_mutex_unlock(&ctx->lock);
+  while (ctx->paused) usleep(100000); /* ctx_check_paused, main.c:152-156: the caller holds no device work here */
 }
 static void ctx_finish(ctx_t *ctx) { /* main.c:174-180 */
   pthread_mutex_lock(&ctx->lock);
@@ -801,6 +808,61 @@ static void usage(const char *name) { /* main.c:750-772 */
   printf("  blf-gen         - create bloom filter from list of hex-encoded hash160\n");
   printf("  blf-check       - check bloom filter for given hex-encoded hash160\n\n");
 }
+/* pause / resume from the terminal (lib/utils.c:559-626, main.c:874-888): /dev/tty in non-canonical mode, one
+   listener thread; 'p' stops the device threads at their next status update, 'r' lets them go on; paused time is
+   taken out of the rate.  Without a controlling terminal (pipes, batch jobs) nothing is installed. */
+static int tty_fd = -1;
+static struct termios tty_orig;
+static bool tty_is_term;
+static void tty_cleanup(void) {
+  if (tty_fd < 0) return;
+  if (tty_is_term) tcsetattr(tty_fd, TCSANOW, &tty_orig);
+  close(tty_fd), tty_fd = -1;
+}
+static void tty_key(ctx_t *ctx, char ch) {
+  if (ch == 'p' && !ctx->paused) {
+    ctx->ts_paused_at = tsnow(), ctx->paused = true;
+    pthread_mutex_lock(&ctx->lock), ctx_print_unlocked(ctx), pthread_mutex_unlock(&ctx->lock);
+  }
+  if (ch == 'r' && ctx->paused) {
+    ctx->paused_time += tsnow() - ctx->ts_paused_at, ctx->paused = false;
+    pthread_mutex_lock(&ctx->lock), ctx_print_unlocked(ctx), pthread_mutex_unlock(&ctx->lock);
+  }
+}
+static void *tty_listener(void *arg) {
+  ctx_t *ctx = arg;
+  for (;;) {
+    int fd = tty_fd;
+    if (fd < 0) break;
+    fd_set fds;
+    FD_ZERO(&fds);
+    FD_SET(fd, &fds);
+    struct timeval tv = {0, 200000};
+    int r = select(fd + 1, &fds, NULL, NULL, &tv);
+    if (r < 0) break;
+    char ch;
+    if (r > 0 && FD_ISSET(fd, &fds) && read(fd, &ch, 1) > 0) tty_key(ctx, ch);
+  }
+  return NULL;
+}
+static void tty_init(ctx_t *ctx) {
+  const char *path = getenv("ECLOOP_HIP_TTY"); /* where the keys come from; a FIFO works too (containers without ptys) */
+  tty_fd = open(path ? path : "/dev/tty", (path ? O_RDWR : O_RDONLY) | O_NONBLOCK);
+  if (tty_fd < 0) return;
+  atexit(tty_cleanup);
+  tty_is_term = tcgetattr(tty_fd, &tty_orig) == 0;
+  if (tty_is_term) {
+    struct termios raw = tty_orig;
+    raw.c_lflag &= ~(tcflag_t)(ICANON | ECHO);
+    tcsetattr(tty_fd, TCSANOW, &raw);
+  } else if (!path) {
+    close(tty_fd), tty_fd = -1;
+    return;
+  }
+  pthread_t th;
+  if (pthread_create(&th, NULL, tty_listener, ctx) == 0) pthread_detach(th);
+}
+
 static void handle_sigint(int sig) {
   fflush(stderr), fflush(stdout);
   printf("\n");
@@ -869,6 +931,7 @@ int main(int argc, const char **argv) {
   printf("----------------------------------------\n");
   fflush(stdout);
   signal(SIGINT, handle_sigint);
+  tty_init(&ctx);
   if (ctx.cmd == CMD_ADD) cmd_add(&ctx);
   if (ctx.cmd == CMD_MUL) cmd_mul(&ctx);
   if (ctx.cmd == CMD_RND) cmd_rnd(&ctx);

@@ -141,3 +141,63 @@ def test_rnd_window_is_an_add_over_the_printed_bounds(cli, tmp_path):
     inside = [l for l in rnd_lines if lo <= int(l.split("\t")[2], 16) <= hi + 2048]
     assert set(add_lines) <= set(rnd_lines) and len(add_lines) > 100
     assert all(int(l.split("\t")[2], 16) < lo + (1 << 21) for l in rnd_lines)
+
+
+@pytest.mark.gpu
+def test_pause_resume_keys(cli, tmp_path):
+    """'p' / 'r' (main.c:874-888, lib/utils.c:559-626): the scan stops at the next status update, the status line offers
+    the other key, the counter stands still, and the paused time is not in the reported time.  The keys are fed through
+    a FIFO named by ECLOOP_HIP_TTY (the GPU boxes have no pty devices; with a terminal the program reads /dev/tty)."""
+    import select
+    import time
+    out, keys = str(tmp_path / "o.txt"), str(tmp_path / "keys")
+    os.mkfifo(keys)
+    t_start = time.time()
+    pr = subprocess.Popen([cli, "add", "-f", os.path.join(GOLD, "btc-puzzles-hash"), "-r", "1000000000:2fffffffff", "-q", "-o", out],
+                          stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                          env=dict(os.environ, ECLOOP_HIP_TTY=keys))
+    kfd = os.open(keys, os.O_WRONLY)  # the program holds the FIFO open O_RDWR, so this does not block for long
+    fd = pr.stderr.fileno()
+    buf = b""
+
+    def pump(seconds):
+        nonlocal buf
+        end = time.time() + seconds
+        while time.time() < end:
+            r, _, _ = select.select([fd], [], [], 0.05)
+            if r:
+                chunk = os.read(fd, 65536)
+                if not chunk:
+                    return False
+                buf += chunk
+        return True
+
+    def last_status():
+        st = [s for s in buf.decode(errors="replace").replace("\x1b[2K", "\r").split("\r") if "Mkeys/s" in s]
+        return counts(st[-1].split("(")[0])[1], st[-1]
+
+    try:
+        deadline = time.time() + 120
+        while b"pause)" not in buf and time.time() < deadline:
+            assert pump(0.2), buf[-500:]
+        assert b"('p' \xe2\x80\x93 pause)" in buf
+        os.write(kfd, b"p")
+        assert pump(1.0)
+        c1, line1 = last_status()
+        assert "resume" in line1, line1
+        assert pump(1.0)
+        c2, line2 = last_status()
+        assert c2 == c1 and "resume" in line2  # nothing advances while paused
+        os.write(kfd, b"r")
+        while pump(0.2):
+            pass
+    finally:
+        os.close(kfd)
+        rc = pr.wait(timeout=120)
+    assert rc == 0
+    final = [s for s in buf.decode(errors="replace").replace("\x1b[2K", "\r").split("\r") if "Mkeys/s" in s][-1]
+    found, checked = counts(final.split("\n")[0])
+    assert checked == 0x2000000000 and found == len(open(out).readlines()) == 2  # puzzles 37 and 38
+    assert "pause" not in final and "resume" not in final
+    secs = float(final.split("s ~")[0])
+    assert secs < time.time() - t_start - 1.5  # the two paused seconds are not in the reported time
