@@ -169,6 +169,7 @@ struct ecl_hip {
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
   uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
+  u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
   // walk state for contiguous continuation
@@ -230,7 +231,7 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   HIPCHK(h, hipEventCreate(&h->ev1));
   HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&h->d_counter, sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_counter, 2 * sizeof(u32)));
   const char* skip = getenv("ECL_HIP_SKIP_SELFTEST");
   if (!(skip && skip[0] == '1')) return ecl_hip_selftest(h);
   return ECL_OK;
@@ -241,7 +242,7 @@ void ecl_hip_close(ecl_hip* h) {
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
-  (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
+  (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -257,6 +258,27 @@ int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
   HIPCHK(h, hipMalloc(&h->d_bloom, nwords * sizeof(u64)));
   HIPCHK(h, hipMemcpy(h->d_bloom, bits, nwords * sizeof(u64), hipMemcpyHostToDevice));
   h->bloom_words = nwords;
+  return ECL_OK;
+}
+
+int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
+  if (!h || (n && !h160)) return ECL_E_ARG;
+  for (uint64_t i = 1; i < n; ++i) {  // strictly increasing in compare_160 order (addr.c:18-26)
+    int c = 0;
+    for (int k = 0; k < 5 && c == 0; ++k) c = h160[i - 1][k] < h160[i][k] ? -1 : (h160[i - 1][k] > h160[i][k] ? 1 : 0);
+    if (c >= 0) {
+      h->err = "ecl_hip_set_list: the list is not sorted and unique";
+      return ECL_E_ARG;
+    }
+  }
+  HIPCHK(h, hipSetDevice(h->dev));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->d_list) HIPCHK(h, hipFree(h->d_list));
+  h->d_list = nullptr, h->list_n = 0;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipMalloc(&h->d_list, n * 20));
+  HIPCHK(h, hipMemcpy(h->d_list, h160, n * 20, hipMemcpyHostToDevice));
+  h->list_n = n;
   return ECL_OK;
 }
 
@@ -296,6 +318,34 @@ static add_kernel_t pick_add_kernel(u32 flags) {
   return endo ? k_add<true, true, true> : k_add<true, true, false>;
 }
 
+// ctx_check_hash's second step (main.c:212-216) for the records a search kernel left in `in`: bsearch over the sorted
+// list (order of compare_160, addr.c:18-26: lexicographic on the five words); members are compacted into `out`.
+// Its own tiny kernel after the search kernel, so the hot loop carries nothing for it (in the loop it cost 0.5 %).
+__global__ void k_list_filter(const ecl_found_dev* in, const u32* counters, u32 in_cap, const u32* list, u64 list_n,
+                              ecl_found_dev* out, u32* out_counter, u32 out_cap) {
+  const u32 n_in = counters[0] < in_cap ? counters[0] : in_cap;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+    const ecl_found_dev r = in[i];
+    u64 lo = 0, hi = list_n;
+    bool hit = false;
+    while (lo < hi) {
+      const u64 mid = lo + ((hi - lo) >> 1);
+      const u32* e = list + mid * 5;
+      int c = 0;
+      for (int k = 4; k >= 0; --k) c = e[k] < r.h160[k] ? -1 : (e[k] > r.h160[k] ? 1 : c);  // word 0 decides last
+      if (c == 0) { hit = true; break; }
+      if (c < 0) lo = mid + 1; else hi = mid;
+    }
+    if (hit) {
+      const u32 idx = atomicAdd(out_counter, 1u);
+      if (idx < out_cap) out[idx] = r;
+    }
+  }
+}
+
+// found records of one call: [0, raw_cap) written by the search kernel; in list mode the confirmed ones are
+// compacted into [raw_cap, raw_cap + cap).  d_counter[0] = records pushed, d_counter[1] = records confirmed.
+#define ECL_LIST_RAW_CAP (1u << 20)
 static int ensure_found(ecl_hip* h, u32 cap) {
   if (cap <= h->found_cap) return ECL_OK;
   if (h->d_found) HIPCHK(h, hipFree(h->d_found));
@@ -303,6 +353,40 @@ static int ensure_found(ecl_hip* h, u32 cap) {
   HIPCHK(h, hipMalloc(&h->d_found, (size_t)cap * sizeof(ecl_found_dev)));
   h->found_cap = cap;
   return ECL_OK;
+}
+
+static u32 raw_cap_of(const ecl_hip* h, u32 cap) { return h->d_list ? (cap > ECL_LIST_RAW_CAP ? cap : ECL_LIST_RAW_CAP) : cap; }
+// after the search kernel has been queued on h->stream: optional list confirm, then counters and records to the host
+static int collect_found(ecl_hip* h, u32 cap, u32 rcap, ecl_found* out, u32* nout, bool keep_endo) {
+  const bool lst = h->d_list != nullptr;
+  if (lst) {
+    const u32 blocks = (rcap + 255) / 256 < 1024 ? (rcap + 255) / 256 : 1024;
+    hipLaunchKernelGGL(k_list_filter, dim3(blocks), dim3(256), 0, h->stream, h->d_found, h->d_counter, rcap, h->d_list, h->list_n,
+                       h->d_found + rcap, h->d_counter + 1, cap);
+    HIPCHK(h, hipGetLastError());
+  }
+  u32 cnts[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(cnts, h->d_counter, sizeof cnts, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const u32 cnt = lst ? cnts[1] : cnts[0];
+  const u32 take = cnt < cap ? cnt : cap;
+  if (take) {
+    std::vector<ecl_found_dev> tmp(take);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found + (lst ? rcap : 0), (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < take; ++i) {
+      out[i].key_offset = tmp[i].key_offset;
+      memcpy(out[i].h160, tmp[i].h160, 20);
+      out[i].endo = keep_endo ? (uint8_t)(tmp[i].tag & 0xff) : 0, out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
+      out[i].pad[0] = out[i].pad[1] = 0;
+    }
+  }
+  *nout = cnt;
+  if (lst && cnts[0] > rcap) {  // the bloom let more through than the staging area holds: some were never looked up
+    h->err = "list mode: more bloom hits in one call than the device staging area holds";
+    *nout = cnts[0];
+    return ECL_E_OVERFLOW;
+  }
+  return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
 }
 
 static int default_lanes(ecl_hip* h) {
@@ -376,7 +460,8 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
-  if ((rc = ensure_found(h, cap ? cap : 1)) != ECL_OK) return rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
 
   const u32 B = h->B;
   const u64 group = 2ull * B;
@@ -443,16 +528,16 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   memcpy(a.jump, h->jump_host, sizeof a.jump);
   a.cxy = h->d_cxy, a.scratch = h->d_scr, a.scratch2 = h->d_scr2;
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
-  a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
   a.B = B, a.T = T, a.nb = nb, a.nkeys = nkeys;
-  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(u32), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(pick_add_kernel(h->flags), dim3(T / 256), dim3(256), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;
-  HIPCHK(h, hipMemcpyAsync(&cnt, h->d_counter, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rc = collect_found(h, cap, rcap, out, &cnt, true);
+  if (rc != ECL_OK && rc != ECL_E_OVERFLOW) return rc;
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->kernel_ms += ms, h->launches += 1, h->keys += nkeys;
@@ -461,20 +546,8 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   const u64 walked = (u64)nb * T * group;
   h->walk_valid = walked == nkeys;
   if (h->walk_valid) h->walk_next = sc_add(k0, sc_mul_u64(s, walked));
-
-  u32 take = cnt < cap ? cnt : cap;
-  if (take) {
-    std::vector<ecl_found_dev> tmp(take);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
-    for (u32 i = 0; i < take; ++i) {
-      out[i].key_offset = tmp[i].key_offset;
-      memcpy(out[i].h160, tmp[i].h160, 20);
-      out[i].endo = (uint8_t)(tmp[i].tag & 0xff), out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
-      out[i].pad[0] = out[i].pad[1] = 0;
-    }
-  }
   *nout = cnt;
-  return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
+  return rc;
 }
 
 // ec_gtable_init (lib/ecc.c:880-905) on the device: every slot is an independent double-and-add
@@ -508,7 +581,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   if (n == 0) return ECL_OK;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
-  if ((rc = ensure_found(h, cap ? cap : 1)) != ECL_OK) return rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
   if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
   std::vector<u32> ks((size_t)n * 8);
   for (u32 i = 0; i < n; ++i) words_of(&ks[(size_t)i * 8], sc_reduce(u256_from(scalars[i])));
@@ -518,8 +592,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   add_args a;
   memset(&a, 0, sizeof a);
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
-  a.found = h->d_found, a.counter = h->d_counter, a.cap = cap;
-  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(u32), h->stream));
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
   dim3 grid((n + 255) / 256), blk(256);
   if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
@@ -527,22 +601,10 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
   HIPCHK(h, hipGetLastError());
   u32 cnt = 0;
-  HIPCHK(h, hipMemcpyAsync(&cnt, h->d_counter, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipFree(d_k));
-  u32 take = cnt < cap ? cnt : cap;
-  if (take) {
-    std::vector<ecl_found_dev> tmp(take);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
-    for (u32 i = 0; i < take; ++i) {
-      out[i].key_offset = tmp[i].key_offset;
-      memcpy(out[i].h160, tmp[i].h160, 20);
-      out[i].endo = 0, out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
-      out[i].pad[0] = out[i].pad[1] = 0;
-    }
-  }
+  rc = collect_found(h, cap, rcap, out, &cnt, false);
+  (void)hipFree(d_k);
   *nout = cnt;
-  return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics (host)
@@ -686,7 +748,9 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   // (2) the walk kernel against the double-and-add kernel: 4096 consecutive keys through an all-ones filter
   const u32 N = 4096, saveB = h->B, saveT = h->Tmax;
   u64* save_bloom = h->d_bloom;
-  const u64 save_words = h->bloom_words;
+  const u64 save_words = h->bloom_words, save_list_n = h->list_n;
+  u32* save_list = h->d_list;
+  h->d_list = nullptr, h->list_n = 0;
   std::vector<u64> ones(64, ~0ull);
   h->d_bloom = nullptr, h->bloom_words = 0;
   h->B = 16, h->Tmax = 256;
@@ -711,6 +775,7 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   // restore the caller's state whatever happened
   if (h->d_bloom) (void)hipFree(h->d_bloom);
   h->d_bloom = save_bloom, h->bloom_words = save_words;
+  h->d_list = save_list, h->list_n = save_list_n;
   h->B = saveB, h->Tmax = saveT;
   if (h->d_tab) (void)hipFree(h->d_tab);
   h->d_tab = nullptr, h->tab_B = 0, h->walk_valid = false;

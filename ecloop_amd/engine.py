@@ -243,6 +243,8 @@ class KeySearch:
         if half_group or max_lanes:
             self.dev.set_geometry(half_group, max_lanes)
         self.dev.set_bloom(flt.words)
+        if flt.hashes is not None:
+            self.dev.set_list(flt.hashes)  # exact confirm on the device too (main.c:212-216); the host check stays
         self.launch_keys = launch_keys
         self.k_checked = 0
         self.k_found = 0

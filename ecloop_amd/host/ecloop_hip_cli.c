@@ -919,6 +919,7 @@ int main(int argc, const char **argv) {
   for (int g = 0; g < ctx.ngpus; ++g) {
     int rc = ecl_hip_open(&ctx.dev[g], g, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
     if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx.dev[g], ctx.blf.bits, ctx.blf.size);
+    if (rc == ECL_OK && ctx.list) rc = ecl_hip_set_list(ctx.dev[g], (const uint32_t(*)[5])ctx.list, ctx.list_count);
     if (rc != ECL_OK) die_ecl(&ctx, g, rc, "open");
   }
   printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", ctx.ngpus, ctx.a33, ctx.a65, ctx.endo);

@@ -12,6 +12,7 @@
  *   ec_gtable_mul xN + ec_jacobi_grprdc
  *     + check_found_mul                     main.c:531-534  ecl_hip_mul_batch()
  *   blf_has(&ctx->blf, h)                   utils.c:308   device probe of the bits given to ecl_hip_set_bloom()
+ *   bsearch(to_find_hashes) in ctx_check_hash main.c:212-216  optional: ecl_hip_set_list() (else on the host, as before)
  *   ctx->check_addr33/65, use_endo, ord_offs main.c:32-34,67  flags / ord_offs of ecl_hip_open()
  *
  * What stays on the host, unchanged in meaning: filter loading (main.c:71-131), the sorted-list confirm after a
@@ -76,6 +77,14 @@ int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
    filter; ecl_hip_get_bloom copies the bit array back (e.g. to write a .blf file, utils.c:328-360). */
 int ecl_hip_bloom_insert(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 int ecl_hip_get_bloom(ecl_hip *h, uint64_t *bits, uint64_t nwords);
+
+/* Optional exact confirm on the device: the second half of ctx_check_hash (main.c:212-216).  h160 = the n sorted,
+   unique list entries (ctx->to_find_hashes, order of compare_160, addr.c:18-26).  With a list resident, add_range /
+   mul_batch report a hash only if it passed the bloom probe AND is in the list (a small kernel after the search
+   kernel looks the bloom hits up by binary search; the list takes 20 bytes per entry of HBM); n = 0 removes the
+   list again (bloom-only reporting).  ECL_E_ARG if the entries are not strictly increasing.  In list mode one call
+   can stage max(cap, 2^20) bloom hits; beyond that it returns ECL_E_OVERFLOW with *nout = the number of bloom hits. */
+int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 
 /* Hash the nkeys keys  start, start+s, ..., start+(nkeys-1)*s  (s = 2^ord_offs; every encoding / endo variant
    selected at open) and report every bloom hit.  start: 256-bit scalar, 4 little-endian u64 limbs, as `fe`.

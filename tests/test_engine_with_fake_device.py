@@ -22,6 +22,7 @@ class FakeDevice:
     def __init__(self, device=0, a33=True, a65=False, endo=False, ord_offs=0):
         self.a33, self.a65, self.endo, self.offs = a33, a65, endo, ord_offs
         self.words = None
+        self.list = None
         self.lanes, self.half = 512, 64
 
     def close(self):
@@ -29,6 +30,9 @@ class FakeDevice:
 
     def set_bloom(self, words):
         self.words = np.array(words, dtype=np.uint64)
+
+    def set_list(self, hashes):
+        self.list = None if hashes is None else {tuple(int(w) for w in h) for h in hashes}
 
     def set_geometry(self, half_group=0, max_lanes=0):
         self.half = half_group or self.half
@@ -64,7 +68,7 @@ class FakeDevice:
             if r.endo in (4, 5):
                 k = k * pow(lam, -2, orc.N) % orc.N
             off = ((k - start) % orc.N) >> self.offs
-            if off < nkeys:
+            if off < nkeys and (self.list is None or tuple(int(w) for w in r.h160) in self.list):
                 recs.append((off, [int(w) for w in r.h160], r.endo, r.compressed))
         arr = np.zeros(min(len(recs), cap), dtype=capi.FOUND_DTYPE)
         for j, (off, h, e, c) in enumerate(recs[:cap]):

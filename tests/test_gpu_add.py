@@ -171,3 +171,57 @@ def test_scan_through_scalar_zero_is_refused():
             assert n == 2048
         finally:
             d.close()
+
+
+def test_device_side_list_confirm():
+    """ecl_hip_set_list = ctx_check_hash's bsearch (main.c:212-216) on the device: with the all-ones bloom every hash
+    is a bloom hit, and only list members come back - for add (with endo images) and for mul."""
+    from ecloop_amd import Device
+    from ecloop_amd.capi import EclError
+    start, n = 0x8000, 4096
+    full = dev_dump(start, n, a33=True, a65=True, endo=True)
+    assert len(full) == n * 12
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(full), 37, replace=False)
+    want = np.unique(np.array([full[i]["h160"] for i in pick], dtype=np.uint32), axis=0)
+    decoys = rng.integers(0, 2**32, (1000, 5), dtype=np.uint64).astype(np.uint32)
+    lst = np.unique(np.concatenate([want, decoys]), axis=0)  # np.unique sorts rows lexicographically = compare_160 order
+    d = Device(0, a33=True, a65=True, endo=True)
+    try:
+        d.set_bloom(ONES)
+        d.set_list(lst)
+        recs, cnt = d.add_range(start, n, cap=4096)
+        assert cnt == len(recs) == len(want)
+        assert sorted(tuple(r["h160"]) for r in recs) == sorted(tuple(w) for w in want)
+        by_h = {tuple(r["h160"]): r for r in full}
+        for r in recs:  # same offsets / tags as the unfiltered dump
+            f = by_h[tuple(r["h160"])]
+            assert (r["key_offset"], r["endo"], r["compressed"]) == (f["key_offset"], f["endo"], f["compressed"])
+        with pytest.raises(EclError):
+            d.set_list(lst[::-1])  # not sorted
+        with pytest.raises(EclError):
+            d.set_list(np.concatenate([lst[:3], lst[2:5]]))  # duplicate
+        recs, cnt = d.add_range(start, 64, cap=4096)  # a refused list leaves the resident one in place
+        assert cnt == sum(1 for r in full if r["key_offset"] < 64 and tuple(r["h160"]) in {tuple(w) for w in want})
+        d.set_list(None)
+        recs, cnt = d.add_range(start, 64, cap=4096)
+        assert cnt == 64 * 12
+    finally:
+        d.close()
+    # mul path: the brainwallet list and keys; all-ones bloom, so the list alone decides -> the reference's 1080 hits
+    from ecloop_amd.engine import load_filter, scalar_from_hex
+    flt = load_filter(os.path.join(GOLD, "btc-bw-hash"))
+    ks = [scalar_from_hex(l.strip()) for l in open(os.path.join(GOLD, "btc-bw-priv")) if l.strip()]
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        recs, cnt = d.mul_batch(ks, cap=8192)
+        assert cnt == 2 * len(ks)
+        d.set_list(flt.hashes)
+        recs, cnt = d.mul_batch(ks, cap=8192)
+        assert cnt == len(recs) == G["make_mul_bw"]["count"]
+        lines = sorted("%s\t%s\t%064x" % ("addr33" if r["compressed"] else "addr65", orc.hex160(r["h160"]), ks[int(r["key_offset"])])
+                       for r in recs)
+        assert orc.digest(lines) == G["make_mul_bw"]["sha256_sorted"]
+    finally:
+        d.close()
