@@ -65,10 +65,11 @@ __global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0
 // hash + probe.  One lane = one scalar: <= 19 mixed additions of table points (64-byte gathers, the 19.9 MB table
 // lives in L2 / Infinity Cache) and one inversion.  The scalar 0 yields no point (the reference emits garbage).
 #define GT_W 14u
+#define MUL_CHUNK (1u << 18)  /* scalars per staged chunk of ecl_hip_mul_batch (8 MB) */
 #define GT_WINDOWS 19u
 #define GT_PER ((1u << GT_W) - 1u)
 template <bool A33, bool A65>
-__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, const u32* __restrict__ gtab, add_args a) {
+__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const u32* __restrict__ gtab, add_args a) {
   u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   u32 kk[9];
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
   }
   fe x, y;
   if (!jac_to_affine(x, y, acc)) return;
-  check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)i);
+  check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
@@ -169,6 +170,10 @@ struct ecl_hip {
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
   uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
+  // `mul`: scalars travel in chunks through two pinned staging buffers, copy engine and kernel overlapped
+  u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr};
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
@@ -243,6 +248,13 @@ void ecl_hip_close(ecl_hip* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(h->d_kbuf[i]);
+    if (h->pin_k[i]) (void)hipHostFree(h->pin_k[i]);
+    if (h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);
+    if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -584,25 +596,39 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
   if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
-  std::vector<u32> ks((size_t)n * 8);
-  for (u32 i = 0; i < n; ++i) words_of(&ks[(size_t)i * 8], sc_reduce(u256_from(scalars[i])));
-  u32* d_k = nullptr;
-  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
-  HIPCHK(h, hipMemcpyAsync(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  if (!h->copy_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)MUL_CHUNK * 32));
+      HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)MUL_CHUNK * 32, hipHostMallocDefault));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+    }
+  }
   add_args a;
   memset(&a, 0, sizeof a);
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
   a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
-  bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
-  dim3 grid((n + 255) / 256), blk(256);
-  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
-  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
-  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, n, h->d_gtab, a);
-  HIPCHK(h, hipGetLastError());
+  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum over 19 x 14 bits is k*G for any
+  // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
+  for (u32 at = 0, c = 0; at < n; at += MUL_CHUNK, ++c) {
+    const u32 m = n - at < MUL_CHUNK ? n - at : MUL_CHUNK, b = c & 1;
+    if (c >= 2) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel two chunks back is done with this pair
+    memcpy(h->pin_k[b], scalars[at], (size_t)m * 32);
+    HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], h->pin_k[b], (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
+    dim3 grid((m + 255) / 256), blk(256);
+    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
+    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
+    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
+  }
   u32 cnt = 0;
   rc = collect_found(h, cap, rcap, out, &cnt, false);
-  (void)hipFree(d_k);
   *nout = cnt;
   return rc;
 }
