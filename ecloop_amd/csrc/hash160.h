@@ -24,16 +24,28 @@ H_FN u32 bsel(u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); }
 // Boolean functions of three words as ONE v_bitop3_b32 (truth table = f(0xF0, 0xCC, 0xAA)).  Written with the
 // builtin because the compiler otherwise splits Ch / Maj / select into disjoint AND terms that it folds into the
 // additions ((e&f) + (~e&g)), which costs more instructions than it saves.
+#define XOR3_C(a, b, c) ((a) ^ (b) ^ (c))
+#define BITSEL_C(m, a, b) (((a) & (m)) | ((b) & ~(m)))
+#define MAJ3_C(a, b, c) (((a) & (b)) | ((c) & ((a) | (b))))
+#define ORN_XOR_C(x, y, z) (((x) | ~(y)) ^ (z))
 #if defined(__HIP_DEVICE_COMPILE__) && ECL_XOR3_BITOP3
-#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x96)
-#define BITSEL(m, a, b) __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA)   /* (m & a) | (~m & b) */
-#define MAJ3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8)     /* majority */
-#define ORN_XOR(x, y, z) __builtin_amdgcn_bitop3_b32(x, y, z, 0x59)  /* (x | ~y) ^ z */
+// The builtin is opaque to constant folding: with all-constant inputs (IV state in the first rounds, the constant
+// words of the padded message) it would be evaluated at run time - hoisted out of the loops, but then its result
+// occupies a VGPR for the whole kernel.  Constant inputs take the plain C form, which folds to a literal.
+#define ECL_ALLCONST(a, b, c) (__builtin_constant_p(a) && __builtin_constant_p(b) && __builtin_constant_p(c))
+H_FN u32 xor3_(u32 a, u32 b, u32 c) { return ECL_ALLCONST(a, b, c) ? XOR3_C(a, b, c) : __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+H_FN u32 bitsel_(u32 m, u32 a, u32 b) { return ECL_ALLCONST(m, a, b) ? BITSEL_C(m, a, b) : __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+H_FN u32 maj3_(u32 a, u32 b, u32 c) { return ECL_ALLCONST(a, b, c) ? MAJ3_C(a, b, c) : __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+H_FN u32 orn_xor_(u32 x, u32 y, u32 z) { return ECL_ALLCONST(x, y, z) ? ORN_XOR_C(x, y, z) : __builtin_amdgcn_bitop3_b32(x, y, z, 0x59); }
+#define XOR3(a, b, c) xor3_(a, b, c)
+#define BITSEL(m, a, b) bitsel_(m, a, b)   /* (m & a) | (~m & b) */
+#define MAJ3(a, b, c) maj3_(a, b, c)       /* majority */
+#define ORN_XOR(x, y, z) orn_xor_(x, y, z) /* (x | ~y) ^ z */
 #else
-#define XOR3(a, b, c) ((a) ^ (b) ^ (c))
-#define BITSEL(m, a, b) (((a) & (m)) | ((b) & ~(m)))
-#define MAJ3(a, b, c) (((a) & (b)) | ((c) & ((a) | (b))))
-#define ORN_XOR(x, y, z) (((x) | ~(y)) ^ (z))
+#define XOR3(a, b, c) XOR3_C(a, b, c)
+#define BITSEL(m, a, b) BITSEL_C(m, a, b)
+#define MAJ3(a, b, c) MAJ3_C(a, b, c)
+#define ORN_XOR(x, y, z) ORN_XOR_C(x, y, z)
 #endif
 
 // ---------------------------------------------------------------- SHA-256
