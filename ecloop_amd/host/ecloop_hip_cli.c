@@ -329,24 +329,28 @@ static void ctx_write_found(ctx_t *ctx, const char *label, const u32 h[5], sc pk
 static bool list_confirm(const ctx_t *ctx, const u32 h[5]) {
   return !ctx->list || bsearch(h, ctx->list, ctx->list_count, 20, cmp160) != NULL;
 }
-/* pk_verify_hash (main.c:248-263): re-derive the hit from its scalar on the device (independent kernel) */
-static void pk_verify_hash(ctx_t *ctx, int g, sc pk, const u32 h[5], bool compressed, int endo) {
-  u64 k[1][4], x[1][4], y[1][4];
-  u8 ok = 0;
-  u32 h33[1][5], h65[1][5];
-  memcpy(k[0], pk.w, 32);
-  int rc = ecl_hip_diag_mulg(ctx->dev[g], k, x, y, &ok, 1);
-  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(ctx->dev[g], x, y, h33, h65, 1);
+/* pk_verify_hash (main.c:248-263) for all hits of one device call: re-derive them from their scalars on the device
+   with the independent double-and-add kernel, in one batch (a round trip per hit costs 0.3 ms) */
+static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *hits, u32 n) {
+  if (!n) return;
+  u64 (*k)[4] = malloc((size_t)n * 32), (*x)[4] = malloc((size_t)n * 32), (*y)[4] = malloc((size_t)n * 32);
+  u32 (*h33)[5] = malloc((size_t)n * 20), (*h65)[5] = malloc((size_t)n * 20);
+  u8 *ok = malloc(n);
+  for (u32 i = 0; i < n; ++i) memcpy(k[i], pks[i].w, 32);
+  int rc = ecl_hip_diag_mulg(ctx->dev[g], k, x, y, ok, n);
+  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(ctx->dev[g], x, y, h33, h65, n);
   if (rc != ECL_OK) die_ecl(ctx, g, rc, "verify");
-  const u32 *r = compressed ? h33[0] : h65[0];
-  if (!ok || memcmp(r, h, 20) != 0) {
-    fprintf(stderr, "[!] error: hash mismatch (compressed: %d endo: %d)\n", compressed, endo);
-    fprintf(stderr, "pk: %016llx%016llx%016llx%016llx\n", (unsigned long long)pk.w[3], (unsigned long long)pk.w[2],
-            (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
+  for (u32 i = 0; i < n; ++i) {
+    const u32 *r = hits[i].compressed ? h33[i] : h65[i], *h = hits[i].h160;
+    if (ok[i] && memcmp(r, h, 20) == 0) continue;
+    fprintf(stderr, "[!] error: hash mismatch (compressed: %d endo: %d)\n", hits[i].compressed, hits[i].endo);
+    fprintf(stderr, "pk: %016llx%016llx%016llx%016llx\n", (unsigned long long)pks[i].w[3], (unsigned long long)pks[i].w[2],
+            (unsigned long long)pks[i].w[1], (unsigned long long)pks[i].w[0]);
     fprintf(stderr, "lh: %08x%08x%08x%08x%08x\n", h[0], h[1], h[2], h[3], h[4]);
     fprintf(stderr, "rh: %08x%08x%08x%08x%08x\n", r[0], r[1], r[2], r[3], r[4]);
     exit(1);
   }
+  free(k), free(x), free(y), free(h33), free(h65), free(ok);
 }
 
 /* ------------------------------------------------------------------------------------------- add */
@@ -377,12 +381,16 @@ static void *add_worker(void *arg) {
       cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap); /* dense filter: rerun with a buffer that fits */
     }
     if (rc != ECL_OK) die_ecl(ctx, j->g, rc, "add_range");
+    u32 kept = 0;
+    sc *pks = cnt ? malloc(sizeof(sc) * cnt) : NULL;
     for (u32 i = 0; i < cnt; ++i) {
       if (!list_confirm(ctx, buf[i].h160)) continue;
-      sc pk = calc_priv(s, ctx->stride_k, buf[i].key_offset, buf[i].endo);
-      pk_verify_hash(ctx, j->g, pk, buf[i].h160, buf[i].compressed, buf[i].endo);
-      ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pk);
+      pks[kept] = calc_priv(s, ctx->stride_k, buf[i].key_offset, buf[i].endo);
+      buf[kept++] = buf[i];
     }
+    pk_verify_hashes(ctx, j->g, pks, buf, kept);
+    for (u32 i = 0; i < kept; ++i) ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pks[i]);
+    free(pks);
     done += n;
     /* status counter: the reference adds job_size (x6 with endo) per job (main.c:431); spread it over the launches */
     u64 before = (u64)((u128)j->status_total * (done - n) / j->keys_total);
@@ -909,7 +917,10 @@ int main(int argc, const char **argv) {
   load_offs_size(&ctx, &args);
   ctx.stride_k = sc_pow2(ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
 
-  int have = ecl_hip_device_count();
+  int have = ecl_hip_device_count(), real = have;
+  /* test hook: ECLOOP_HIP_SHARE_GPU=N runs N device threads over the GPUs that exist (device g mod count), so the
+     multi-GPU sharding / merging logic can be exercised on a one-GPU box */
+  if (have > 0 && getenv("ECLOOP_HIP_SHARE_GPU")) have = atoi(getenv("ECLOOP_HIP_SHARE_GPU")) > 0 ? atoi(getenv("ECLOOP_HIP_SHARE_GPU")) : have;
   if (have <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
   u64 want = args_uint(&args, "-t", (u64)have);
   ctx.ngpus = (int)(want < 1 ? 1 : want > (u64)have ? (u64)have : want);
@@ -917,7 +928,7 @@ int main(int argc, const char **argv) {
   if (ctx.cmd == CMD_MUL) ctx.ngpus = 1;
   u32 flags = (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0);
   for (int g = 0; g < ctx.ngpus; ++g) {
-    int rc = ecl_hip_open(&ctx.dev[g], g, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
+    int rc = ecl_hip_open(&ctx.dev[g], g % real, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
     if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx.dev[g], ctx.blf.bits, ctx.blf.size);
     if (rc == ECL_OK && ctx.list) rc = ecl_hip_set_list(ctx.dev[g], (const uint32_t(*)[5])ctx.list, ctx.list_count);
     if (rc != ECL_OK) die_ecl(&ctx, g, rc, "open");

@@ -23,10 +23,10 @@ def cli():
     return build_host_cli()
 
 
-def run(cli, args, stdin_path=None, out=None):
+def run(cli, args, stdin_path=None, out=None, env=None):
     cmd = [cli] + args + (["-q", "-o", out] if out else [])
     pr = subprocess.run(cmd, stdin=open(stdin_path, "rb") if stdin_path else subprocess.DEVNULL, stdout=subprocess.PIPE,
-                        stderr=subprocess.PIPE, timeout=600)
+                        stderr=subprocess.PIPE, timeout=600, env=env)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
     status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
     lines = sorted(l.rstrip("\n") for l in open(out)) if out and os.path.exists(out) else []
@@ -76,6 +76,26 @@ def test_add_known_answers(cli, tmp_path):
         g = G[name]
         assert lines == sorted(g["lines"])
         assert counts(status) == (g["status_found"], g["status_checked"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ngpu", [2, 3, 8])
+def test_add_sharded_over_device_threads(cli, tmp_path, ngpu):
+    """`-t N` = N device threads, the range cut into N contiguous shards.  On a one-GPU box the test hook
+    ECLOOP_HIP_SHARE_GPU lets the N threads share the device: found lists and status counters must not depend on N."""
+    env = dict(os.environ, ECLOOP_HIP_SHARE_GPU=str(ngpu))
+    puz = os.path.join(GOLD, "btc-puzzles-hash")
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    for name, args in [("make_add_8000_ffffff", ["-f", puz, "-r", "8000:ffffff"]),
+                       ("endo_cu_list_8000_fffff", ["-f", puz, "-r", "8000:fffff", "-a", "cu", "-endo"]),
+                       ("dump33_overrun_9000_9801", ["-f", ones, "-r", "9000:9801"]),
+                       ("dump_cu_endo_8000_87ff", ["-f", ones, "-r", "8000:87ff", "-a", "cu", "-endo"])]:
+        lines, status, stdout = run(cli, ["add", "-t", str(ngpu)] + args, out=str(tmp_path / (name + ".txt")), env=env)
+        g = G[name]
+        assert "gpus: %d " % ngpu in stdout
+        assert len(lines) == g.get("count", len(g.get("lines", []))) and digest(lines) == g["sha256_sorted"], name
+        assert counts(status) == (g["status_found"], g["status_checked"]), name
 
 
 @pytest.mark.gpu
