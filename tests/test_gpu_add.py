@@ -225,3 +225,33 @@ def test_device_side_list_confirm():
         assert orc.digest(lines) == G["make_mul_bw"]["sha256_sorted"]
     finally:
         d.close()
+
+
+def test_mult_verify_gtable_against_double_and_add():
+    """the reference's hidden `mult-verify` (lib/bench.c:143-166): fixed-base window multiplication == double-and-add
+    for k = 2..16001, here through the hashes of both kernels; plus scalars that exercise every window, >= n, and 0."""
+    from ecloop_amd import Device
+    ks = list(range(2, 16002))
+    rng = np.random.default_rng(11)
+    ks += [int.from_bytes(rng.bytes(32), "big") for _ in range(4096)]            # any 256-bit value, some >= n
+    ks += [orc.N - 1, orc.N + 1, orc.N + 12345, (1 << 256) - 1, 1 << 255, (1 << 14) - 1, 1 << 14, 1 << 252]
+    ks += [sum(((1 << 14) - 1) << (14 * w) for w in range(0, 19, 2)) % (1 << 256)]
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        recs, cnt = d.mul_batch(ks + [0, orc.N], cap=2 * len(ks) + 8)           # k = 0 (mod n): infinity, skipped
+        assert cnt == len(recs) == 2 * len(ks)
+        xs, ys, ok = d.diag_mulg([k % orc.N for k in ks])
+        h33, h65 = d.diag_hash160(xs, ys)
+        assert all(ok)
+        got33 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if r["compressed"]}
+        got65 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if not r["compressed"]}
+        assert len(got33) == len(got65) == len(ks)
+        for i in range(len(ks)):
+            assert got33[i] == tuple(h33[i]) and got65[i] == tuple(h65[i]), hex(ks[i])
+        # and against the oracle for a few (the double-and-add kernel itself is pinned elsewhere)
+        for i in (0, 1, 15999, len(ks) - 1, len(ks) - 5):
+            x, y = orc.point_of(ks[i] % orc.N)
+            assert tuple(orc.hash160(x, y, True)) == got33[i]
+    finally:
+        d.close()
