@@ -37,9 +37,11 @@ OPS_PER_KEY = 313 + 350 + 2570
 # peak: one VALU wave-instruction per SIMD per 4 clocks (measured, profiles/ubench_r01.txt): 256 CU x 4 SIMD x 64 lanes
 # x 2.4 GHz / 4 = 39.3 T int32 lane-ops/s
 PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12
-# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 141.0 B + WRITE_SIZE 18.1 B per key:
-# two 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.9 TB/s.
+# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 103.9 B + WRITE_SIZE 18.1 B per key:
+# 1.6 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.5 TB/s.
 TRAFFIC_BYTES_PER_KEY = 121.9
+HBM_PEAK_GBS = 8000.0
+VALU_BUSY_PCT = 97.6  # rocprofv3 --pmc VALUBusy on the 2^32-key launch (profiles/r01_pmc_valu.txt)
 
 
 def splitmix_hashes(n, seed):
@@ -237,7 +239,10 @@ def main():
                      "frac": round(achieved / PEAK_TOPS, 4), "traffic": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY),
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.txt)",
                      "kernel": "k_add<addr33>", "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch),
-                     "ops_per_key": OPS_PER_KEY, "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0},
+                     "ops_per_key": OPS_PER_KEY, "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0,
+                     "valu_busy_pct_profiled": VALU_BUSY_PCT,
+                     "hbm_gbs": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9, 1) if ms_launch else 0,
+                     "hbm_frac_of_peak": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_launch else 0},
     }
     if not headline:
         hashes_per_key = len(args.addr) * (6 if args.endo else 1)
