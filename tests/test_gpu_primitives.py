@@ -83,3 +83,43 @@ def test_selftest_passes_and_leaves_state_alone(dev):
     dev.set_bloom(w)
     dev.selftest()
     assert (dev.get_bloom(len(w)) == w).all()
+
+
+def test_c_abi_error_codes():
+    """error behaviour of the boundary (include/ecloop_hip.h): plain int codes, nothing printed, nothing exits"""
+    import ctypes as C
+    from ecloop_amd import capi
+    lib = capi.load()
+    P = C.c_void_p
+    h = P()
+    assert lib.ecl_hip_open(C.byref(h), 99, capi.ADDR33, 0) == -3 and not h          # ECL_E_NODEV
+    assert lib.ecl_hip_open(C.byref(h), 0, 0, 0) == -1                                # no address type: ECL_E_ARG
+    assert lib.ecl_hip_open(C.byref(h), 0, capi.ADDR33, 256) == -1                    # ord_offs > 255
+    assert lib.ecl_hip_open(C.byref(h), 0, capi.ADDR33 | 8, 0) == -1                  # unknown flag
+    assert lib.ecl_hip_open(None, 0, capi.ADDR33, 0) == -1
+    assert lib.ecl_hip_open(C.byref(h), 0, capi.ADDR33, 0) == 0 and h
+    try:
+        start = (C.c_uint64 * 4)(0x8000, 0, 0, 0)
+        out = np.zeros(16, dtype=capi.FOUND_DTYPE)
+        n = C.c_uint32(7)
+        assert lib.ecl_hip_add_range(h, start, 2048, out.ctypes.data, 16, C.byref(n)) == -5 and n.value == 0   # ECL_E_NOBLOOM
+        assert lib.ecl_hip_mul_batch(h, start, 1, out.ctypes.data, 16, C.byref(n)) == -5
+        words = np.full(4, 0xFFFFFFFFFFFFFFFF, np.uint64)
+        assert lib.ecl_hip_set_bloom(h, None, 4) == -1 and lib.ecl_hip_set_bloom(h, words.ctypes.data, 0) == -1
+        assert lib.ecl_hip_set_bloom(h, words.ctypes.data, 4) == 0
+        assert lib.ecl_hip_add_range(h, None, 2048, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_add_range(h, start, 2048, None, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_add_range(h, start, 2048, out.ctypes.data, 16, None) == -1
+        assert lib.ecl_hip_add_range(h, start, 0, out.ctypes.data, 16, C.byref(n)) == 0 and n.value == 0      # empty range
+        assert lib.ecl_hip_add_range(h, start, 2048, out.ctypes.data, 16, C.byref(n)) == -4 and n.value == 2048  # ECL_E_OVERFLOW
+        assert sorted(int(k) for k in out["key_offset"]) == sorted(set(int(k) for k in out["key_offset"])) and all(out["key_offset"] < 2048)
+        assert lib.ecl_hip_add_range(h, start, 2048, None, 0, C.byref(n)) == -4 and n.value == 2048            # count only
+        zero = (C.c_uint64 * 4)(0, 0, 0, 0)
+        assert lib.ecl_hip_add_range(h, zero, 2048, out.ctypes.data, 16, C.byref(n)) == -6                     # ECL_E_RANGE
+        assert b"private key 0" in lib.ecl_hip_last_error(h)
+        assert lib.ecl_hip_set_geometry(h, 1, 0) == -1 and lib.ecl_hip_set_geometry(h, 1 << 17, 0) == -1
+        for rc in range(-7, 1):
+            assert lib.ecl_hip_strerror(rc)
+    finally:
+        lib.ecl_hip_close(h)
+    lib.ecl_hip_close(None)  # no-op
