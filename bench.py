@@ -32,16 +32,24 @@ sys.path.insert(0, ROOT)
 RANGE_A = 0x100000000  # configs[1] / SURVEY §8d: add -r 100000000:1ffffffff
 FILTER_N = 10_000_000
 PLANTED = 16
-# algorithmic work per addr33 key: 313 IMAD + 350 ALU (EC) + 2570 ALU (hash160)
-OPS_PER_KEY = 313 + 350 + 2570
-# peak: one VALU wave-instruction per SIMD per 4 clocks (measured, profiles/ubench_r01.txt): 256 CU x 4 SIMD x 64 lanes
-# x 2.4 GHz / 4 = 39.3 T int32 lane-ops/s
-PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12
-# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 103.9 B + WRITE_SIZE 18.1 B per key:
-# 1.6 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.5 TB/s.
-TRAFFIC_BYTES_PER_KEY = 121.9
+# Work per addr33 key, priced as SURVEY.md §8d prescribes: the static VALU instruction count per key from the gfx950
+# assembly (tools/isa_mix.py over the hot blocks, weighted by trip count; the PMC count SQ_INSTS_VALU agrees: 3198 per
+# key) times the issue cost of each class measured by the dependency-free microbenchmark (profiles/ubench_r01.txt,
+# SIMD-cycles per wave-instruction at the nominal clock):
+#   432 v_mad_u64_u32 x 4.61 + 618 double-rate VOP2 (add/sub/and/or/xor/mov) x 2.55 + 2148 other VALU x 4.23
+#   = 12 653 SIMD-cycles per 64 keys = 3163 lane-cycles per key (16 lanes per SIMD-cycle).
+# (SURVEY's estimate before any code existed: 313 IMAD + 350 ALU + 2570 ALU = 3233 ops, ~4.2 k lane-cycles.)
+VALU_PER_KEY = {"mad64": 432, "fast_vop2": 618, "other": 2148}
+ISSUE_CYCLES = {"mad64": 4.61, "fast_vop2": 2.55, "other": 4.23}
+OPS_PER_KEY = sum(VALU_PER_KEY.values())
+LANE_CYCLES_PER_KEY = sum(VALU_PER_KEY[k] * ISSUE_CYCLES[k] for k in VALU_PER_KEY) / 4.0
+# peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-cycles/s (one 64-wide VALU instruction per SIMD per 4 clocks)
+PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 117.6 B + WRITE_SIZE 18.0 B per key:
+# 1.8 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.5 TB/s.
+TRAFFIC_BYTES_PER_KEY = 135.6
 HBM_PEAK_GBS = 8000.0
-VALU_BUSY_PCT = 97.6  # rocprofv3 --pmc VALUBusy on the 2^32-key launch (profiles/r01_pmc_valu.txt)
+VALU_BUSY_PCT = 99.0  # rocprofv3 --pmc VALUBusy on the 2^32-key launch (profiles/r01_pmc_valu.txt)
 
 
 def splitmix_hashes(n, seed):
@@ -226,7 +234,7 @@ def main():
     value = total_keys / dt / 1e6
     ms_launch = kernel_ms / max(launches, 1)
     keys_per_launch = kkeys / max(launches, 1)
-    achieved = keys_per_launch * OPS_PER_KEY / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
+    achieved = keys_per_launch * LANE_CYCLES_PER_KEY / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
     res = {
         "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -235,11 +243,11 @@ def main():
                                f".blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
                    "keys_per_gpu_per_step": nkeys, "parallelism": f"range-sharded x{world}, no collective",
                    "found_per_step": len(ks.found), "planted_found": PLANTED - len(missing)},
-        "roofline": {"bound": "valu-int32", "achieved": round(achieved, 3), "peak": round(PEAK_TOPS, 2), "unit": "Tops/s",
+        "roofline": {"bound": "valu-int32", "achieved": round(achieved, 3), "peak": round(PEAK_TOPS, 2), "unit": "T lane-cycles/s",
                      "frac": round(achieved / PEAK_TOPS, 4), "traffic": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY),
                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.txt)",
                      "kernel": "k_add<addr33>", "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch),
-                     "ops_per_key": OPS_PER_KEY, "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0,
+                     "valu_instr_per_key": OPS_PER_KEY, "lane_cycles_per_key": round(LANE_CYCLES_PER_KEY, 1), "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0,
                      "valu_busy_pct_profiled": VALU_BUSY_PCT,
                      "hbm_gbs": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9, 1) if ms_launch else 0,
                      "hbm_frac_of_peak": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_launch else 0},

@@ -116,51 +116,88 @@ struct cand_queue {
   u32 count;   // wave-uniform, < 64 between calls
 };
 
-__device__ __forceinline__ void cand_confirm(const add_args& a, const cand_queue& q, u32 slot, bool live) {
-  if (!live) return;
-  u32 h[5];
+#ifndef ECL_TWO_LEVEL_QUEUE
+#define ECL_TWO_LEVEL_QUEUE 1
+#endif
+struct cand_rec {
+  u64 off;
+  u32 h[5], tag;
+};
+__device__ __forceinline__ cand_rec cand_load(const cand_queue& q, u32 slot) {
+  cand_rec r;
+  r.off = (u64)q.mem[slot] | (u64)q.mem[ECL_Q_SLOTS + slot] << 32;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) h[i] = q.mem[(2 + i) * ECL_Q_SLOTS + slot];
-  if (bloom_stage2(a.bloom, h)) {
-    const u64 off = (u64)q.mem[slot] | (u64)q.mem[ECL_Q_SLOTS + slot] << 32;
-    const u32 tag = q.mem[7 * ECL_Q_SLOTS + slot];
-    found_push(a, off, h, tag & 0xff, (tag >> 8) & 1);
-  }
+  for (int i = 0; i < 5; ++i) r.h[i] = q.mem[(2 + i) * ECL_Q_SLOTS + slot];
+  r.tag = q.mem[7 * ECL_Q_SLOTS + slot];
+  return r;
 }
-__device__ __forceinline__ void cand_drain64(const add_args& a, cand_queue& q) {
-  const u32 lane = threadIdx.x & 63u;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  cand_confirm(a, q, (q.head + lane) & (ECL_Q_SLOTS - 1), true);
-  q.head = (q.head + 64) & (ECL_Q_SLOTS - 1);
-  q.count -= 64;
-}
-__device__ __forceinline__ void cand_flush(const add_args& a, cand_queue& q) {  // end of the kernel: the remainder
-  const u32 lane = threadIdx.x & 63u;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  cand_confirm(a, q, (q.head + lane) & (ECL_Q_SLOTS - 1), lane < q.count);
-  q.count = 0;
-}
-// Filter test of one hash; q == nullptr: no queue (`mul` kernel), everything in place.  With a queue the call must
-// be reached by ALL lanes of the wave together (head / count are wave-uniform state): lanes whose key is outside
-// the range come along with live = false.
-__device__ __forceinline__ void cand_push(const add_args& a, cand_queue* q, bool pass, u64 off, const u32 h[5], u32 tag) {
+// append the records of the lanes with `pass` (ballot + mbcnt compaction); returns true when 64 or more are waiting.
+// Must be reached by ALL lanes of the wave together (head / count are wave-uniform state).
+__device__ __forceinline__ bool cand_append(cand_queue& q, bool pass, u64 off, const u32 h[5], u32 tag) {
   const u64 m = __builtin_amdgcn_ballot_w64(pass);
-  if (m == 0) return;
+  if (m == 0) return false;
   if (pass) {
     const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-    const u32 slot = (q->head + q->count + below) & (ECL_Q_SLOTS - 1);
-    q->mem[slot] = (u32)off;
-    q->mem[ECL_Q_SLOTS + slot] = (u32)(off >> 32);
+    const u32 slot = (q.head + q.count + below) & (ECL_Q_SLOTS - 1);
+    q.mem[slot] = (u32)off;
+    q.mem[ECL_Q_SLOTS + slot] = (u32)(off >> 32);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) q->mem[(2 + i) * ECL_Q_SLOTS + slot] = h[i];
-    q->mem[7 * ECL_Q_SLOTS + slot] = tag;
+    for (int i = 0; i < 5; ++i) q.mem[(2 + i) * ECL_Q_SLOTS + slot] = h[i];
+    q.mem[7 * ECL_Q_SLOTS + slot] = tag;
   }
-  q->count += (u32)__builtin_popcountll(m);
-  if (q->count >= 64) cand_drain64(a, *q);
+  q.count += (u32)__builtin_popcountll(m);
+  return q.count >= 64;
 }
+// take up to 64 records off the ring: lane i gets record i (valid for i < n)
+__device__ __forceinline__ cand_rec cand_take(cand_queue& q, bool& valid) {
+  const u32 lane = threadIdx.x & 63u;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const u32 n = q.count < 64 ? q.count : 64;
+  valid = lane < n;
+  cand_rec r = cand_load(q, (q.head + lane) & (ECL_Q_SLOTS - 1));
+  q.head = (q.head + n) & (ECL_Q_SLOTS - 1);
+  q.count -= n;
+  return r;
+}
+// the two rings of a wave: A = survivors of probe 0 (37 % of all hashes at the .blf design density), B = survivors of
+// the middle stage (probes 1-2: 14 % of A; one probe for multi-GB filters: 37 %).  A is drained 64 at a time without
+// a loop; only B runs the remaining probes with the early-out loop, where the wave iterates until its slowest lane
+// is done.  Per hash and wave: 68 VALU instructions for the whole filter test instead of 96 with one ring.
+struct cand_queues {
+  cand_queue a, b;
+};
+__device__ __forceinline__ void cand_finish(const add_args& a, cand_queue& qb) {  // up to 64 records of ring B
+  bool valid;
+  const cand_rec r = cand_take(qb, valid);
+  const int from = ECL_TWO_LEVEL_QUEUE ? ECL_STAGE1_PROBES + (bloom_mid_two(a.bloom) ? 2 : 1) : ECL_STAGE1_PROBES;
+  if (valid && bloom_probes_from(a.bloom, r.h, from))
+    found_push(a, r.off, r.h, r.tag & 0xff, (r.tag >> 8) & 1);
+}
+__device__ __forceinline__ void cand_mid(const add_args& a, cand_queues& q) {  // up to 64 records of ring A -> ring B
+  bool valid;
+  const cand_rec r = cand_take(q.a, valid);
+  const bool pass = valid && bloom_mid(a.bloom, r.h, bloom_mid_two(a.bloom));
+  if (cand_append(q.b, pass, r.off, r.h, r.tag)) cand_finish(a, q.b);
+}
+__device__ __forceinline__ void cand_push(const add_args& a, cand_queues* q, bool pass, u64 off, const u32 h[5], u32 tag) {
+#if ECL_TWO_LEVEL_QUEUE
+  if (cand_append(q->a, pass, off, h, tag)) cand_mid(a, *q);
+#else
+  if (cand_append(q->b, pass, off, h, tag)) cand_finish(a, q->b);
+#endif
+}
+__device__ __forceinline__ void cand_flush(const add_args& a, cand_queues& q) {  // end of the kernel: the remainders
+#if ECL_TWO_LEVEL_QUEUE
+  cand_mid(a, q);  // A holds < 64
+#endif
+  cand_finish(a, q.b);  // B holds < 128: at most two rounds
+  cand_finish(a, q.b);
+}
+// Filter test of one hash; q == nullptr: no queue (`mul` kernel), everything in place.  With a queue the call must
+// be reached by ALL lanes of the wave together: lanes whose key is outside the range come along with live = false.
 // (Deferring the stage-1 test by one hash - loads in flight under the next hash160 - was measured: no gain, the
 // other waves of the SIMD already cover the probe latency.)
-__device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, bool live, u64 off, const u32 h[5], u32 endo,
+__device__ __forceinline__ void filter_check(const add_args& a, cand_queues* q, bool live, u64 off, const u32 h[5], u32 endo,
                                              u32 compressed) {
   const bool pass = live && bloom_stage1(a.bloom, h);
   if (!q) {
@@ -174,7 +211,7 @@ __device__ __forceinline__ void filter_check(const add_args& a, cand_queue* q, b
 // (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327).
 // x: magnitude <= 4, y: magnitude <= 3.
 template <bool A33, bool A65, bool ENDO>
-__device__ __forceinline__ void check_point(const add_args& a, cand_queue* q, bool live, fe x, fe y, u64 off) {
+__device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, bool live, fe x, fe y, u64 off) {
   u32 xw[3][8], yw[2][8], par = 0;
   if (ENDO) {
     const u32 bw[8] = FE_BETA1_W;
@@ -229,9 +266,10 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queue* q, bo
 #endif
 template <bool A33, bool A65, bool ENDO>
 __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
-  __shared__ u32 q_mem[4][8 * ECL_Q_SLOTS];  // one candidate ring per wave
-  cand_queue q;
-  q.mem = q_mem[threadIdx.x >> 6], q.head = 0, q.count = 0;
+  __shared__ u32 q_mem[4][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave
+  cand_queues q;
+  q.a.mem = q_mem[threadIdx.x >> 6][0], q.a.head = 0, q.a.count = 0;
+  q.b.mem = q_mem[threadIdx.x >> 6][1], q.b.head = 0, q.b.count = 0;
   const u32 g = blockIdx.x * 256u + threadIdx.x;
   const u32 T = a.T, B = a.B;
   if (g >= T) return;

@@ -814,7 +814,8 @@ static void usage(const char *name) { /* main.c:750-772 */
   printf("  -endo           - use endomorphism (default: false)\n");
   printf("\nOther commands:\n");
   printf("  blf-gen         - create bloom filter from list of hex-encoded hash160\n");
-  printf("  blf-check       - check bloom filter for given hex-encoded hash160\n\n");
+  printf("  blf-check       - check bloom filter for given hex-encoded hash160\n");
+  printf("  bench           - run benchmark of the device paths (add per address type / endo, mul)\n\n");
 }
 /* pause / resume from the terminal (lib/utils.c:559-626, main.c:874-888): /dev/tty in non-canonical mode, one
    listener thread; 'p' stops the device threads at their next status update, 'r' lets them go on; paused time is
@@ -877,6 +878,62 @@ static void handle_sigint(int sig) {
   exit(sig);
 }
 
+/* `bench` (the reference's `bench` / `bench-gtable`, lib/bench.c, time its CPU primitives): here the device paths,
+   through the C ABI, with an empty filter: keys/s of the add walk per address / endo selection, scalars/s of mul. */
+static int run_bench(args_t *args) {
+  if (ecl_hip_device_count() <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
+  u64 lg = args_uint(args, "-n", 31);
+  if (lg < 20 || lg > 36) lg = 31;
+  static const struct { const char *name; u32 flags; } cfg[] = {
+      {"add -a c", ECL_ADDR33}, {"add -a u", ECL_ADDR65}, {"add -a cu", ECL_ADDR33 | ECL_ADDR65},
+      {"add -a c -endo", ECL_ADDR33 | ECL_ENDO}, {"add -a cu -endo", ECL_ADDR33 | ECL_ADDR65 | ECL_ENDO}};
+  u64 zeros[64] = {0};
+  const u64 start[4] = {0x100000000ull, 0, 0, 0};
+  ecl_found hit[16];
+  for (size_t c = 0; c < sizeof cfg / sizeof cfg[0]; ++c) {
+    ecl_hip *d = NULL;
+    int rc = ecl_hip_open(&d, 0, cfg[c].flags, 0);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(d, zeros, 64);
+    u64 n = 1ull << (lg - ((cfg[c].flags & ECL_ENDO) ? 2 : 0));
+    u32 cnt = 0;
+    if (rc == ECL_OK) rc = ecl_hip_add_range(d, start, n, hit, 16, &cnt); /* warm-up: table, centres, scratch */
+    if (rc == ECL_OK) rc = ecl_hip_reset_timing(d);
+    u64 t0 = tsnow();
+    if (rc == ECL_OK) rc = ecl_hip_add_range(d, start, n, hit, 16, &cnt);
+    u64 t1 = tsnow();
+    double kms = 0;
+    u64 launches = 0, keys = 0;
+    if (rc == ECL_OK) rc = ecl_hip_get_timing(d, &kms, &launches, &keys);
+    if (rc != ECL_OK) { fprintf(stderr, "[!] bench %s: %s (%s)\n", cfg[c].name, ecl_hip_strerror(rc), d ? ecl_hip_last_error(d) : ""); return 1; }
+    int hashes = ((cfg[c].flags & ECL_ADDR33) ? 1 : 0) + ((cfg[c].flags & ECL_ADDR65) ? 1 : 0);
+    if (cfg[c].flags & ECL_ENDO) hashes *= 6;
+    printf("%-18s 2^%-2d keys: %9.2f Mkeys/s (kernel %9.2f) ~ %9.2f M hash160/s\n", cfg[c].name,
+           (int)(lg - ((cfg[c].flags & ECL_ENDO) ? 2 : 0)), n / ((t1 - t0 ? t1 - t0 : 1) / 1000.0) / 1e6, keys / (kms / 1000.0) / 1e6,
+           hashes * (keys / (kms / 1000.0)) / 1e6);
+    fflush(stdout);
+    ecl_hip_close(d);
+  }
+  { /* mul: 2^22 pseudo-random scalars, addr33 + addr65 */
+    ecl_hip *d = NULL;
+    u32 n = 1u << 22, cnt = 0;
+    u64 (*ks)[4] = malloc((size_t)n * 32);
+    u64 x = 0x9E3779B97F4A7C15ull;
+    for (u32 i = 0; i < n; ++i)
+      for (int j = 0; j < 4; ++j) x ^= x << 13, x ^= x >> 7, x ^= x << 17, ks[i][j] = x;
+    int rc = ecl_hip_open(&d, 0, ECL_ADDR33 | ECL_ADDR65, 0);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(d, zeros, 64);
+    if (rc == ECL_OK) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt); /* warm-up: builds the window table */
+    u64 t0 = tsnow();
+    for (int r = 0; r < 4 && rc == ECL_OK; ++r) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt);
+    u64 t1 = tsnow();
+    if (rc != ECL_OK) { fprintf(stderr, "[!] bench mul: %s\n", ecl_hip_strerror(rc)); return 1; }
+    printf("%-18s 2^22 keys: %9.2f M it/s (scalars copied from host memory)\n", "mul -a cu", 4.0 * n / ((t1 - t0 ? t1 - t0 : 1) / 1000.0) / 1e6);
+    free(ks);
+    ecl_hip_close(d);
+  }
+  return 0;
+}
+
 int main(int argc, const char **argv) {
   setlocale(LC_NUMERIC, "");
   args_t args = {argc, argv};
@@ -884,6 +941,7 @@ int main(int argc, const char **argv) {
   if (argc > 1) {
     if (!strcmp(argv[1], "blf-gen")) return blf_gen(&args), 0;
     if (!strcmp(argv[1], "blf-check")) return blf_check(&args), 0;
+    if (!strcmp(argv[1], "bench")) return run_bench(&args);
     if (!strcmp(argv[1], "add")) ctx.cmd = CMD_ADD;
     if (!strcmp(argv[1], "mul")) ctx.cmd = CMD_MUL;
     if (!strcmp(argv[1], "rnd")) ctx.cmd = CMD_RND;
