@@ -328,11 +328,17 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
         bool valid = true;  // wave-uniform
         if (which < 2) {
           // lambda = (+-Gy - Y) / (Gx - X); x3 = lambda^2 - X - Gx; y3 = lambda (X - x3) - Y   (main.c:379-386)
-          fe s = which == 0 ? fe_sub(gy, Y) : fe_neg(fe_add(gy, Y), 2);  // magnitude 3
+          // +-Gy - Y, magnitude 3.  The table side (Gy + 2p or 3p - Gy) is wave-uniform like `which`: selected on
+          // the scalar unit, so the vector side is one subtraction per limb (written as a select of two vector
+          // results the compiler emits both and nine v_cndmask)
+          const fe c = which == 0 ? fe_add(gy, fe_neg(fe_zero(), 1)) : fe_neg(gy, 2);
+          fe s;
+#pragma unroll
+          for (int l = 0; l < FE_LIMBS; ++l) s.n[l] = c.n[l] - Y.n[l];
           fe lam = fe_mul(s, invk);
           px = fe_add(fe_sqr(lam), nxg);                                   // magnitude 4
           py = fe_sub(fe_mul(lam, fe_add(X, fe_neg(px, 4))), Y);           // X - px: magnitude 6; py: magnitude 3
-          off = which == 0 ? base + B + 1 + i : base + (B - 1 - i);
+          off = base + (which == 0 ? B + 1 + i : B - 1 - i);  // scalar select, one 64-bit add
           valid = which == 1 || i + 1 < B;
         } else {
           px = X, py = Y, off = base + B;
