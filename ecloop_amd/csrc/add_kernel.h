@@ -342,6 +342,13 @@ __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
           valid = which == 1 || i + 1 < B;
         } else {
           px = X, py = Y, off = base + B;
+          // the centre itself, once per B iterations: keep the copies of X and Y inside this branch (left alone, the
+          // compiler copies them into px / py at the head of EVERY iteration and overwrites them: 18 moves per key)
+#pragma unroll
+          for (int l = 0; l < FE_LIMBS; ++l) {
+            FE_HIDE24(px.n[l]);
+            FE_HIDE24(py.n[l]);
+          }
         }
         if (valid) check_point<A33, A65, ENDO>(a, &q, off < a.nkeys, px, py, off);
       }

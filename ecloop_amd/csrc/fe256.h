@@ -201,7 +201,13 @@ FE_FN void fe_mul_tail(fe& r, u64 c, u64 d, u32 t8) {
   d += c * (FE_R1 >> 5) + r.n[1];
   r.n[1] = (u32)d & FE_M;
   d >>= 29;
-  r.n[2] += (u32)d;
+  // the carry into limb 2 as an opaque 32-bit value: left visible, the backend keeps limb 2 as the untruncated 64-bit
+  // sum and multiplies the NEXT product by it as a 64 x 32 bit value (one more v_mad_u64_u32 and two moves per use:
+  // 9 uses per multiplication) - the same dropped-truncation family as the FE_HIDE24 bug, harmless only because the
+  // carry is tiny
+  u32 cy = (u32)d;
+  FE_HIDE24(cy);
+  r.n[2] += cy;
 }
 
 // lib/ecc.c:307-347. Inputs with m1*m2 <= 7, output magnitude 1.
