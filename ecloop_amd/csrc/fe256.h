@@ -187,25 +187,28 @@ FE_FN fe fe_neg(const fe& a, u32 m) {
 FE_FN fe fe_sub(const fe& a, const fe& b) { return fe_add(a, fe_neg(b, 1)); }
 
 // shared tail of fe_mul / fe_sqr: column 8, then the fold of everything above 2^256
-FE_FN void fe_mul_tail(fe& r, u64 c, u64 d, u32 t8) {
-  // what is left in d sits at 2^(29*17) = 2^(29*8) * 2^261
-  c += d * FE_R0 + t8;
+FE_FN void fe_mul_tail(fe& r, u64 c, u64 d64, u32 t8) {
+  // what is left in d sits at 2^(29*17) = 2^(29*8) * 2^261.  It is small: column 16 = a8*b8 + carry < 7 * 2^48 + 2^29,
+  // so d < 2^23 - a 32-bit factor (left 64 bits wide, each product with it costs a second multiply instruction)
+  u32 d = (u32)d64;
+  FE_HIDE24(d);
+  c += (u64)d * FE_R0 + t8;
   r.n[8] = (u32)c & FE_TOP;
   FE_HIDE24(r.n[8]);
   c >>= 24;
-  c += d * ((u64)FE_R1 << 5);
+  c += (u64)d << 13;  // d * (R1 << 5)
   // c * 2^256 = c * (2^32 + 977): limbs 0 and 1, then a short carry
-  d = c * (FE_R0 >> 5) + r.n[0];
-  r.n[0] = (u32)d & FE_M;
-  d >>= 29;
-  d += c * (FE_R1 >> 5) + r.n[1];
-  r.n[1] = (u32)d & FE_M;
-  d >>= 29;
+  u64 e = c * (FE_R0 >> 5) + r.n[0];
+  r.n[0] = (u32)e & FE_M;
+  e >>= 29;
+  e += c * (FE_R1 >> 5) + r.n[1];
+  r.n[1] = (u32)e & FE_M;
+  e >>= 29;
   // the carry into limb 2 as an opaque 32-bit value: left visible, the backend keeps limb 2 as the untruncated 64-bit
   // sum and multiplies the NEXT product by it as a 64 x 32 bit value (one more v_mad_u64_u32 and two moves per use:
   // 9 uses per multiplication) - the same dropped-truncation family as the FE_HIDE24 bug, harmless only because the
   // carry is tiny
-  u32 cy = (u32)d;
+  u32 cy = (u32)e;
   FE_HIDE24(cy);
   r.n[2] += cy;
 }
