@@ -133,3 +133,25 @@ def test_parse_range_errors():
     for bad in ("800:ffff", "8000", "ffff:8000"):  # (an end above p cannot occur: -r values are reduced mod n first)
         with pytest.raises(ValueError):
             parse_range(bad)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench.json is a bench.py line from the GPU box: the driver's contract fields, the roofline and the
+    cpu_baseline objects must all be there, and bench.py must still print the same field names."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench.json")).readline())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"].startswith("Mkeys/sec (add, addr33)") and line["unit"] == "Mkeys/s" and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 2e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["cpu_baseline"]["kind"] in ("reference", "port")
+    assert abs(line["value"] - line["config"]["keys_per_gpu_per_step"] * line["n_gpus"] / (line["ms_per_step"] * 1e3)) / line["value"] < 1e-3
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for k in ('"ms_per_step"', '"higher_is_better"', '"vs_baseline"', '"roofline"', '"cpu_baseline"', '"traffic"', '"frac"', '"cores"', '"sample"'):
+        assert k in src, k
