@@ -1,0 +1,18 @@
+"""A short slice of tools/fuzz_gpu.py inside the GPU suite: random ranges / geometries / selections / strides / filters,
+found lists compared with the oracle (the long runs are recorded under profiles/)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_scans_equal_the_oracle(seed):
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "8", str(seed)], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, timeout=300)
+    out = pr.stdout.decode(errors="replace")
+    assert pr.returncode == 0 and "ALL EQUAL" in out, out[-2000:]
