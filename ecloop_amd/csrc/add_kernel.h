@@ -104,11 +104,11 @@ __device__ __forceinline__ void found_push(const add_args& a, u64 off, const u32
   }
 }
 
-// ---- two-stage filter test -----------------------------------------------------------------------------------
-// Stage 1 (bloom.h: one probe) runs on every hash.  Its survivors (37 % at the .blf design density) are not finished on
-// the spot - a handful of live lanes would drag all 64 lanes of the wave through up to 18 more dependent probes
-// (measured: 6 % of the kernel with 14 % survivors) - but parked in a per-wave ring in LDS; whenever 64 have gathered, each lane takes
-// one and the wave runs stage 2 densely.  Wave-private: no barrier, no atomics; records: key offset, hash160, tag.
+// ---- staged filter test ---------------------------------------------------------------------------------------
+// Probe 0 (bloom.h) runs on every hash.  Its survivors (37 % at the .blf design density) are not finished on the
+// spot - the live lanes would drag all 64 lanes of the wave through up to 19 more dependent probes (measured: 6 % of
+// the kernel) - but parked in per-wave rings in LDS and finished 64 at a time (cand_queues below).  Wave-private:
+// no barrier, no atomics; records: key offset, hash160, tag.
 #define ECL_Q_SLOTS 128u
 struct cand_queue {
   u32* mem;    // this wave's slice of LDS: 8 fields x ECL_Q_SLOTS words, field-major (conflict-free for lane-contiguous slots)
@@ -259,10 +259,10 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, b
 // waves per SIMD the register allocator must leave room for (256-thread blocks: blocks per CU = this value)
 // 1: load the next prefix product one iteration ahead (10 more live VGPRs across the hash), 0: load at use
 #ifndef ECL_PREFETCH
-#define ECL_PREFETCH 0  /* measured: 0 -> 9.70, 1 -> 9.35 Gkeys/s: register pressure beats latency hiding at 3 waves/SIMD */
+#define ECL_PREFETCH 0  /* measured early in the round: 0 -> 9.70, 1 -> 9.35 Gkeys/s; with the final kernel both give the same rate */
 #endif
 #ifndef ECL_ADD_WAVES
-#define ECL_ADD_WAVES 3  /* measured: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33) */
+#define ECL_ADD_WAVES 3  /* measured early in the round: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33); final kernel: 2 is 2 % slower, 3 and 4 equal */
 #endif
 template <bool A33, bool A65, bool ENDO>
 __global__ void __launch_bounds__(256, ECL_ADD_WAVES) k_add(const add_args a) {
