@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already set on the boxes)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
