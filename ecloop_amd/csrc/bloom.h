@@ -57,13 +57,14 @@ FE_FN u64 bloom_index(const u64 a[5], int probe) {
 }
 FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (b.bits[bloom_mod(b, idx >> 6)] >> (idx & 63)) & 1; }
 
-// lib/utils.c:308-326 in two stages.  Stage 1: probe 0 alone (at the `.blf` design density 0.375 it rejects 62 % of
-// the hashes; ECL_STAGE1_PROBES = 2 issues probes 0 and 1 together and rejects 86 %).  Stage 2: the remaining
-// probes, one at a time with the reference's early-out.  Measured on MI355X, addr33 over 2^32 keys: 54 MB filter
-// 11.95 vs 11.95 Gkeys/s (1 vs 2 probes), 5.9 GB filter 11.09 vs 10.69 - a multi-GB filter is bound by the number
-// of random HBM sectors touched, and one probe first touches 1.59 per hash instead of 2.22.  bloom_has() = both stages; the add kernel queues the survivors of stage 1 per wave and runs
-// stage 2 on 64 of them at a time (add_kernel.h: cand_queue), because inside the hot loop a few surviving lanes would
-// keep the whole wave iterating.
+// lib/utils.c:308-326 in stages.  Stage 1: probe 0 alone (at the `.blf` design density 0.375 it rejects 62 % of the
+// hashes; ECL_STAGE1_PROBES = 2 would issue probes 0 and 1 together and reject 86 %).  Then the remaining probes, one
+// at a time with the reference's early-out (bloom_stage2); bloom_has() = both.  The add kernel parks the survivors of
+// stage 1 in per-wave rings and finishes them 64 at a time in two steps - bloom_mid (one or two probes, no loop),
+// then bloom_probes_from (the early-out loop) - because inside the hot loop a few surviving lanes would keep the whole
+// wave iterating (add_kernel.h: cand_queues).  Measured on MI355X, addr33 over 2^32 keys, 1 vs 2 probes in stage 1:
+// 54 MB filter 11.95 vs 11.95 Gkeys/s, 5.9 GB filter 11.09 vs 10.69 - a multi-GB filter is bound by the number of
+// random HBM sectors touched, and one probe first touches 1.59 per hash instead of 2.22.
 FE_FN void bloom_words_of(u64 a[5], const u32 h[5]) {
   a[0] = (u64)h[0] << 32 | h[1];
   a[1] = (u64)h[2] << 32 | h[3];
