@@ -114,6 +114,9 @@ def cpu_baseline(words, sample_keys_log2_max=33):
         lines = sorted(l.strip() for l in open(out)) if os.path.exists(out) else []
         return float(m.group(2)), float(m.group(1)), dt, lines
 
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
     for binary in refs:
         if not os.path.exists(binary):
             continue

@@ -38,6 +38,8 @@ def main():
     ref = os.path.join(ROOT, "oracle", "_ref", "ecloop_sane")
     cli = build_host_cli()
     tmp = tempfile.mkdtemp(prefix="eclparity")
+    import atexit, shutil
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
     blf = os.path.join(tmp, "bench.blf")
     d = Device(0)
     size, offs, _ = bench.build_filter(d, bench.RANGE_A, 1 << 32)

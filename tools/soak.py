@@ -19,6 +19,8 @@ from ecloop_amd.engine import blf_save  # noqa: E402
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 cli = build_host_cli()
 tmp = tempfile.mkdtemp(prefix="eclsoak")
+import atexit, shutil
+atexit.register(shutil.rmtree, tmp, ignore_errors=True)
 blf, out = os.path.join(tmp, "bench.blf"), os.path.join(tmp, "found.txt")
 d = Device(0)
 size, offs, _ = bench.build_filter(d, bench.RANGE_A, 1 << 32)
