@@ -34,12 +34,12 @@ FILTER_N = 10_000_000
 PLANTED = 16
 # Work per addr33 key, priced as SURVEY.md §8d prescribes: the static VALU instruction count per key from the gfx950
 # assembly (tools/isa_mix.py over the hot blocks, weighted by trip count: 3042, plus the amortised inversion and
-# candidate-ring drains; total taken from the PMC count SQ_INSTS_VALU: 3115 per key) times the issue cost of each class measured by the dependency-free microbenchmark (profiles/ubench_r01.txt,
+# candidate-ring drains; total taken from the PMC count SQ_INSTS_VALU: 3127 per key) times the issue cost of each class measured by the dependency-free microbenchmark (profiles/ubench_r01.txt,
 # SIMD-cycles per wave-instruction at the nominal clock):
-#   422 v_mad_u64_u32 x 4.61 + 600 double-rate VOP2 (add/sub/and/or/xor/mov) x 2.55 + 2093 other VALU x 4.23
-#   = 12 329 SIMD-cycles per 64 keys = 3082 lane-cycles per key (16 lanes per SIMD-cycle).
+#   422 v_mad_u64_u32 x 4.61 + 606 double-rate VOP2 (add/sub/and/or/xor/mov) x 2.55 + 2099 other VALU x 4.23
+#   = 12 370 SIMD-cycles per 64 keys = 3092 lane-cycles per key (16 lanes per SIMD-cycle).
 # (SURVEY's estimate before any code existed: 313 IMAD + 350 ALU + 2570 ALU = 3233 ops, ~4.2 k lane-cycles.)
-VALU_PER_KEY = {"mad64": 422, "fast_vop2": 600, "other": 2093}
+VALU_PER_KEY = {"mad64": 422, "fast_vop2": 606, "other": 2099}
 ISSUE_CYCLES = {"mad64": 4.61, "fast_vop2": 2.55, "other": 4.23}
 OPS_PER_KEY = sum(VALU_PER_KEY.values())
 LANE_CYCLES_PER_KEY = sum(VALU_PER_KEY[k] * ISSUE_CYCLES[k] for k in VALU_PER_KEY) / 4.0
