@@ -60,6 +60,57 @@ __global__ void __launch_bounds__(256) k_init_centres(const u32* __restrict__ c0
   fe_st_words2(cxy + 2 * (size_t)T + g, T, y);
 }
 
+// The same centres with the inversion shared: one thread owns INIT_R consecutive lanes, walks them as Jacobian points
+// (base from the ladder, then +D each), parks X, Y, Z and the running product of the Z's in `tmp` (the chain scratch
+// of the add kernel, idle at this point; planes of T / INIT_R words), inverts the product once and unwinds
+// (Montgomery's trick, as lib/ecc.c:522-540 does for the reference's batch).  44 multiplications per centre
+// instead of ~410 (most of them the per-lane inversion): 1.6 ms -> 0.25 ms for 2^20 lanes.
+#define INIT_R 16u
+__global__ void __launch_bounds__(256) k_init_centres_batched(const u32* __restrict__ c0, const u32* __restrict__ ladder,
+                                                               uint4* __restrict__ cxy, u32 T, u32* __restrict__ tmp) {
+  const u32 nt = T / INIT_R, t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nt) return;
+  const u32 g0 = t * INIT_R;
+  jac acc;
+  acc.X = fe_ldw(c0), acc.Y = fe_ldw(c0 + 8), acc.Z = fe_one(), acc.inf = 0;
+#pragma unroll 1
+  for (int j = 4; j < 32; ++j) {
+    if ((g0 >> j) == 0) break;
+    if ((g0 >> j) & 1u) acc = jac_madd(acc, fe_ldw(ladder + j * 16), fe_ldw(ladder + j * 16 + 8));
+  }
+  const fe dx = fe_ldw(ladder), dy = fe_ldw(ladder + 8);
+  fe prod = fe_one();
+#pragma unroll 1
+  for (u32 r = 0; r < INIT_R; ++r) {
+    if (r) acc = jac_madd(acc, dx, dy);
+    const fe z = acc.inf ? fe_one() : acc.Z;  // infinity cannot occur for a scan the range check let through
+    u32* p = tmp + (size_t)r * 36 * nt + t;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      p[(size_t)l * nt] = acc.X.n[l], p[(size_t)(9 + l) * nt] = acc.Y.n[l];
+      p[(size_t)(18 + l) * nt] = z.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+    }
+    prod = fe_mul(prod, z);
+  }
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = INIT_R; r-- > 0;) {
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, Z, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      Z.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe zi = fe_mul(inv, pre);
+    inv = fe_mul(inv, Z);
+    const fe zi2 = fe_sqr(zi);
+    const fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
+    fe_st_words2(cxy + g0 + r, T, x);
+    fe_st_words2(cxy + 2 * (size_t)T + g0 + r, T, y);
+  }
+}
+
 // `mul` command body (main.c:530-534, 458-479): public key of each scalar by the fixed-base window method of
 // ec_gtable_mul (lib/ecc.c:876-929: W = 14, 19 windows, table slot (2^14-1)*i + b-1 = b * 2^(14 i) * G), then
 // hash + probe.  One lane = one scalar: <= 19 mixed additions of table points (64-byte gathers, the 19.9 MB table
@@ -412,9 +463,10 @@ static int default_lanes(ecl_hip* h) {
   // Oversubscribe: with exactly the resident number of lanes every wave of the chip is in the same phase at the same
   // time (prefix products, then the inversion chain, then the hash-heavy walk back); with several times more blocks
   // than slots the dispatcher staggers them and the phases overlap.  Measured on addr33: 196608 lanes (resident)
-  // 10.9 Gkeys/s, 786432 11.5, 1048576 12.0, 2097152 12.1.  The chains cost lanes * B * 36 bytes of HBM
-  // (2^20 lanes, B = 1024: 38 GB), so the factor is cut back if memory is short.
-  u64 lanes = 1ull << 20;
+  // 10.9 Gkeys/s, 786432 11.5, 1048576 12.0, 2097152 12.1 (final kernel: 12.49 / 12.63 at 2^20 / 2^21, no more
+  // beyond).  The chains cost lanes * B * 36 bytes of HBM (2^21 lanes, B = 1024: 77 GB of the 288), so the factor is
+  // cut back if memory is short.
+  u64 lanes = 1ull << 21;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     while (lanes > resident && lanes * h->B * 36ull > free_b / 3) lanes /= 2;
@@ -497,6 +549,16 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
       return ECL_E_RANGE;
     }
   }
+  size_t need = (size_t)T * B * 2;
+  if (h->scr_elems < need) {
+    if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
+    if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
+    h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
+    HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
+    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(u32)));
+    h->scr_elems = need;
+  }
+
   bool cont = h->walk_valid && h->walk_T == T && u256_eq(h->walk_next, k0);
   if (!cont) {
     // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G
@@ -519,22 +581,16 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
       HIPCHK(h, hipMalloc(&h->d_cxy, (size_t)T * 4 * sizeof(uint4)));
       h->cxy_T = T;
     }
-    hipLaunchKernelGGL(k_init_centres, dim3(T / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32, h->d_cxy, T);
+    if (B >= 8)  // the chain scratch (T * B * 36 bytes) holds the 144 bytes per lane the batched set-up parks
+      hipLaunchKernelGGL(k_init_centres_batched, dim3((T / INIT_R + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32,
+                         h->d_cxy, T, (u32*)h->d_scr);
+    else
+      hipLaunchKernelGGL(k_init_centres, dim3(T / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32, h->d_cxy, T);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->walk_T = T;
   }
-  size_t need = (size_t)T * B * 2;
-  if (h->scr_elems < need) {
-    if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
-    if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
-    h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
-    HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
-    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(u32)));
-    h->scr_elems = need;
-  }
-
   add_args a;
   a.tab = h->d_tab;
   memcpy(a.jump, h->jump_host, sizeof a.jump);
