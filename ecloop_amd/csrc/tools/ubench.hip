@@ -149,6 +149,138 @@ __global__ void k_add_dep(uint32_t* out, uint32_t seed) {
   if (r == 0x12345) out[0] = r;
 }
 
+// mixed streams: do double-rate ops keep their rate next to 4-cycle ops, and does their order matter?
+// per iteration 32 instructions: 16 v_add_u32 + 16 v_alignbit_b32 on independent registers
+__global__ void k_mix_alternating(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+        asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(a), "v"(b));
+      }
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];
+  if (s == 0x12345) out[0] = s;
+}
+__global__ void k_mix_grouped(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(a), "v"(b));
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];
+  if (s == 0x12345) out[0] = s;
+}
+// 8 adds per 24 alignbits (the hash's ratio), alternating 1:3
+__global__ void k_mix_1to3(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+      asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(a), "v"(b));
+      asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[(i + 3) & 7]) : "v"(a), "v"(b));
+      asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[(i + 5) & 7]) : "v"(a), "v"(b));
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];
+  if (s == 0x12345) out[0] = s;
+}
+
+__global__ void k_mix_pairs(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i + 1]) : "v"(a));
+        asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(a), "v"(b));
+        asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i + 1]) : "v"(a), "v"(b));
+      }
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];
+  if (s == 0x12345) out[0] = s;
+}
+// 2 adds per 12 four-cycle ops (one RIPEMD step pair): 2 of 14
+__global__ void k_mix_pair_in_14(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[u]) : "v"(a));
+      asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[u + 2]) : "v"(a));
+#pragma unroll
+      for (int i = 0; i < 14; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[i & 7]) : "v"(a), "v"(b));
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];
+  if (s == 0x12345) out[0] = s;
+}
+
+// ---- calibration in REAL shader cycles: every wave brackets its loop with s_memtime (shader clock) and
+// s_memrealtime (constant 100 MHz); out[2..] collects the maxima, main() prints the sustained clock and the
+// SIMD-cycles per wave-instruction that follow from it (independent of the nominal clock the table above assumes).
+#define CAL_BEGIN uint64_t c0_ = __builtin_readcyclecounter(), w0_ = wall_clock64();
+#define CAL_END(out)                                                                         \
+  {                                                                                          \
+    uint64_t c1_ = __builtin_readcyclecounter(), w1_ = wall_clock64();                       \
+    if ((threadIdx.x & 63) == 0) {                                                           \
+      atomicMax((unsigned long long*)(out) + 1, (unsigned long long)(c1_ - c0_));            \
+      atomicMax((unsigned long long*)(out) + 2, (unsigned long long)(w1_ - w0_));            \
+    }                                                                                        \
+  }
+#define KCAL(NAME, BODY)                                                     \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                       \
+    uint32_t r[8], q[8], a = seed ^ threadIdx.x, b = a * 7 + 1;              \
+    uint64_t m[2] = {a, b};                                                  \
+    for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = b * (i + 5);      \
+    CAL_BEGIN                                                                \
+    for (int it = 0; it < ITERS; ++it) { BODY }                              \
+    CAL_END(out)                                                             \
+    uint32_t s = (uint32_t)(m[0] ^ m[1]);                                    \
+    for (int i = 0; i < 8; ++i) s ^= r[i] ^ q[i];                            \
+    if (s == 0x12345) out[0] = s;                                            \
+  }
+#define I_ADD(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[(i) & 7]) : "v"(a));
+#define I_ROT(i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(q[(i) & 7]) : "v"(a), "v"(b));
+#define I_MAD(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(m[(i) & 1]) : "v"(a), "v"(b) : "vcc");
+#define I_BOP(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(q[(i) & 7]) : "v"(a), "v"(b));
+#define I_AD3(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r[(i) & 7]) : "v"(a), "v"(b));
+#define R4(M, i) M(i) M(i + 1) M(i + 2) M(i + 3)
+#define R16(M) R4(M, 0) R4(M, 4) R4(M, 8) R4(M, 12)
+#define R32(M) R16(M) R16(M)
+KCAL(k_cal_rot, R32(I_ROT))
+KCAL(k_cal_add, R32(I_ADD))
+KCAL(k_cal_bop, R32(I_BOP))
+KCAL(k_cal_ad3, R32(I_AD3))
+KCAL(k_cal_hashmix, R4(I_ROT, 0) I_BOP(1) I_AD3(0) I_ROT(2) I_ROT(3) I_ROT(4) I_BOP(5) I_BOP(6) I_AD3(1) I_ADD(2) I_AD3(3) I_ROT(5) I_ROT(6) I_BOP(7) I_AD3(4) I_ROT(0) I_ROT(1) I_ROT(2) I_BOP(3) I_AD3(5) I_ADD(6) I_ROT(4) I_BOP(5) I_AD3(7) I_ROT(6) I_ADD(0) I_ROT(7) I_BOP(0) I_AD3(1))
+KCAL(k_cal_mad, R32(I_MAD))
+KCAL(k_cal_alt, R4(I_ADD, 0) R4(I_ROT, 0) R4(I_ADD, 4) R4(I_ROT, 4) R4(I_ADD, 0) R4(I_ROT, 0) R4(I_ADD, 4) R4(I_ROT, 4))        /* runs of 4 */
+KCAL(k_cal_alt1, I_ADD(0) I_ROT(0) I_ADD(1) I_ROT(1) I_ADD(2) I_ROT(2) I_ADD(3) I_ROT(3) I_ADD(4) I_ROT(4) I_ADD(5) I_ROT(5) I_ADD(6) I_ROT(6) I_ADD(7) I_ROT(7) \
+                 I_ADD(0) I_ROT(0) I_ADD(1) I_ROT(1) I_ADD(2) I_ROT(2) I_ADD(3) I_ROT(3) I_ADD(4) I_ROT(4) I_ADD(5) I_ROT(5) I_ADD(6) I_ROT(6) I_ADD(7) I_ROT(7))  /* runs of 1 */
+KCAL(k_cal_run16, R16(I_ADD) R16(I_ROT))                                                                                           /* runs of 16 */
+KCAL(k_cal_hashmix_g10, R4(I_ROT, 0) R4(I_ROT, 4) R4(I_ROT, 0) I_ROT(4) R4(I_AD3, 0) R4(I_AD3, 4) I_AD3(0) R4(I_BOP, 0) I_BOP(4) I_BOP(5) I_BOP(6) I_ADD(0) I_ADD(1) I_ADD(2))
+KCAL(k_cal_hashmix_g5, R4(I_ROT, 0) I_ROT(4) I_ROT(5) R4(I_AD3, 0) I_AD3(4) R4(I_BOP, 0) I_ADD(0) R4(I_ROT, 0) I_ROT(6) I_ROT(7) I_ROT(1) R4(I_AD3, 4) I_BOP(4) I_BOP(5) I_BOP(6) I_ADD(1) I_ADD(2))
+KCAL(k_cal_madrot, I_MAD(0) I_ROT(0) I_MAD(1) I_ROT(1) I_MAD(0) I_ROT(2) I_MAD(1) I_ROT(3) I_MAD(0) I_ROT(4) I_MAD(1) I_ROT(5) I_MAD(0) I_ROT(6) I_MAD(1) I_ROT(7) \
+                   I_MAD(0) I_ROT(0) I_MAD(1) I_ROT(1) I_MAD(0) I_ROT(2) I_MAD(1) I_ROT(3) I_MAD(0) I_ROT(4) I_MAD(1) I_ROT(5) I_MAD(0) I_ROT(6) I_MAD(1) I_ROT(7))
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; double per_iter; };
 
@@ -174,6 +306,9 @@ int main(int argc, char** argv) {
       {"v_fma_f32", k_fma_f32, 32}, {"v_pk_fma_f32", k_pk_fma_f32, 32}, {"v_pk_add_u16", k_pk_add_u16, 32},
       {"v_add_f64", k_add_f64, 32}, {"v_mul_f64", k_mul_f64, 32}, {"v_fma_f64", k_fma_f64, 32},
       {"v_mad_u64_u32 dependent chain", k_mad_u64_dep, 32}, {"v_add_u32 dependent chain", k_add_dep, 32},
+      {"mix 16 add + 16 alignbit, alternating", k_mix_alternating, 32}, {"mix 16 add + 16 alignbit, grouped by 8", k_mix_grouped, 32},
+      {"mix 8 add + 24 alignbit (1:3)", k_mix_1to3, 32},
+      {"mix 16 add + 16 alignbit, in pairs", k_mix_pairs, 32}, {"mix 4 add (2 pairs) + 28 alignbit", k_mix_pair_in_14, 32},
   };
   int waves_per_simd = argc > 1 ? atoi(argv[1]) : 8;
   int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD
@@ -190,6 +325,25 @@ int main(int argc, char** argv) {
     double rate = instrs / (ms * 1e-3);
     double cyc = (cus * 4.0 * clk) / rate;  // SIMD-cycles per wave-instr
     printf("%-36s %14.1f %16.2f\n", e.name, rate / 1e9, cyc);
+  }
+  printf("\n# calibration in real shader cycles (s_memtime / s_memrealtime inside the kernels)\n");
+  printf("%-44s %12s %20s\n", "stream (32 instr per iteration)", "clock GHz", "real cyc/instr/SIMD");
+  struct { const char* name; kern_t k; } cs[] = {
+      {"v_alignbit_b32 only", k_cal_rot}, {"v_add_u32 only", k_cal_add}, {"v_bitop3_b32 only", k_cal_bop}, {"v_add3_u32 only", k_cal_ad3},
+      {"hash-like mix (rot/bitop3/add3, 3 single adds)", k_cal_hashmix},
+      {"same multiset, the 10 fast ops in one run", k_cal_hashmix_g10}, {"same multiset, fast ops in two runs of 5", k_cal_hashmix_g5}, {"v_mad_u64_u32 only", k_cal_mad},
+      {"add / alignbit, runs of 1", k_cal_alt1}, {"add / alignbit, runs of 4", k_cal_alt}, {"add / alignbit, runs of 16", k_cal_run16},
+      {"mad / alignbit alternating", k_cal_madrot}};
+  for (auto& c : cs) {
+    hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemset(out, 0, 64));
+    hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    CHECK(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
+    double cyc = (double)h[1], ghz = h[2] ? cyc / ((double)h[2] / 100e6) / 1e9 : 0;
+    printf("%-44s %12.3f %20.2f\n", c.name, ghz, cyc / ((double)ITERS * 32 * waves_per_simd));
   }
   return 0;
 }
