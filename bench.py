@@ -183,6 +183,11 @@ def main():
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
 
+    from ecloop_amd.build import build_library
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing
+    if dist is not None:
+        dist.barrier()
     from ecloop_amd.engine import Filter, KeySearch, calc_priv
     nkeys = 1 << args.keys_log2
     start = RANGE_A + rank * nkeys
