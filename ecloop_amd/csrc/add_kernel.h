@@ -262,7 +262,7 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, b
 #define ECL_PREFETCH 0  /* measured early in the round: 0 -> 9.70, 1 -> 9.35 Gkeys/s; with the final kernel both give the same rate */
 #endif
 #ifndef ECL_ADD_WAVES
-#define ECL_ADD_WAVES 4  /* measured early in the round: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33); final kernel: 2 is 2 % slower,
+#define ECL_ADD_WAVES 4  /* measured early in the round: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33); final kernel: 2 is 2 % slower, 5 is 0.9 % and 6 is 4.8 % slower,
                            4 is 0.2-0.5 % faster than 3 except for -a cu -endo (0.4 % slower: it stays at 3) */
 #endif
 template <bool A33, bool A65, bool ENDO>
