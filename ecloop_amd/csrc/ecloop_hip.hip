@@ -230,7 +230,8 @@ struct ecl_hip {
   u32* d_counter = nullptr;
   // walk state for contiguous continuation
   bool walk_valid = false;
-  u32 walk_T = 0;
+  u32 walk_T = 0, walk_B = 0;
+  bool B_auto = true;  // half group not fixed by the caller: short calls take a smaller one (see ecl_hip_add_range)
   u256 walk_next;  // scalar (mod n) the resident centres are positioned for
   u32 jump_host[16];
   // timing
@@ -349,7 +350,7 @@ int ecl_hip_set_geometry(ecl_hip* h, uint32_t half_group, uint32_t max_lanes) {
   if (!h) return ECL_E_ARG;
   if (half_group) {
     if (half_group < 2 || half_group > (1u << 16)) return ECL_E_ARG;
-    h->B = half_group;
+    h->B = half_group, h->B_auto = false;
   }
   if (max_lanes) h->Tmax = (max_lanes + 255u) & ~255u;
   h->walk_valid = false;
@@ -527,7 +528,14 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
 
-  const u32 B = h->B;
+  // The table for half group h->B holds the tables of all smaller ones as prefixes.  A call too short to give every
+  // one of the Tmax lanes a whole group takes a smaller half group (down to 256) instead of fewer lanes: the walk only
+  // reaches its rate when the chip is oversubscribed with blocks in different phases (2^29 keys: 11.5 Gkeys/s with
+  // 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion: 270 / 2B multiplications
+  // per key).  Contiguous calls of one size keep one geometry, so they still continue the resident walk.
+  u32 B = h->B;
+  if (h->B_auto)
+    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
   const u64 group = 2ull * B;
   u64 ngroups = (nkeys + group - 1) / group;
   // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
@@ -559,7 +567,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     h->scr_elems = need;
   }
 
-  bool cont = h->walk_valid && h->walk_T == T && u256_eq(h->walk_next, k0);
+  bool cont = h->walk_valid && h->walk_T == T && h->walk_B == B && u256_eq(h->walk_next, k0);
   if (!cont) {
     // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G
     u256 d = sc_mul_u64(s, group);
@@ -589,7 +597,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->walk_T = T;
+    h->walk_T = T, h->walk_B = B;
   }
   add_args a;
   a.tab = h->d_tab;
@@ -829,13 +837,14 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   }
   // (2) the walk kernel against the double-and-add kernel: 4096 consecutive keys through an all-ones filter
   const u32 N = 4096, saveB = h->B, saveT = h->Tmax;
+  const bool saveAuto = h->B_auto;
   u64* save_bloom = h->d_bloom;
   const u64 save_words = h->bloom_words, save_list_n = h->list_n;
   u32* save_list = h->d_list;
   h->d_list = nullptr, h->list_n = 0;
   std::vector<u64> ones(64, ~0ull);
   h->d_bloom = nullptr, h->bloom_words = 0;
-  h->B = 16, h->Tmax = 256;
+  h->B = 16, h->Tmax = 256, h->B_auto = false;
   const uint64_t start[4] = {0x0123456789abcdefull, 0x1f, 0, 0};
   const u32 per_key = ((h->flags & ECL_ADDR33) ? 1 : 0) + ((h->flags & ECL_ADDR65) ? 1 : 0);
   const u32 cap = N * per_key * ((h->flags & ECL_ENDO) ? 6 : 1);
@@ -858,7 +867,7 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   if (h->d_bloom) (void)hipFree(h->d_bloom);
   h->d_bloom = save_bloom, h->bloom_words = save_words;
   h->d_list = save_list, h->list_n = save_list_n;
-  h->B = saveB, h->Tmax = saveT;
+  h->B = saveB, h->Tmax = saveT, h->B_auto = saveAuto;
   if (h->d_tab) (void)hipFree(h->d_tab);
   h->d_tab = nullptr, h->tab_B = 0, h->walk_valid = false;
   h->kernel_ms = 0, h->launches = 0, h->keys = 0;

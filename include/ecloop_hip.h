@@ -101,7 +101,8 @@ int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_
 /* Geometry of the walk: half_group = table points per group (the reference fixes 1024: GROUP_INV_SIZE/2,
    main.c:17), max_lanes = keys walked concurrently.  0 keeps the default (1024 and 2^21 lanes; the walk parks
    lanes * half_group * 36 bytes of prefix products in HBM - 77 GB at the default - and takes fewer lanes by itself
-   when free memory is short).  Results do not depend on either. */
+   when free memory is short; while half_group is left at its default, calls shorter than lanes * 2048 keys use a half
+   group of 512 or 256 so that the lanes stay oversubscribed).  Results do not depend on either. */
 int ecl_hip_set_geometry(ecl_hip *h, uint32_t half_group, uint32_t max_lanes);
 /* Current geometry.  One "sweep" = lanes * 2 * half_group keys: calls whose nkeys is a multiple of it keep every
    lane equally busy (no tail) and can be continued by the next contiguous call without re-initialisation. */

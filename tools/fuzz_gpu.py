@@ -59,11 +59,13 @@ def main():
             cuts = []
         if cuts and rnd.random() < 0.5:  # cuts on sweep boundaries continue the resident walk, others re-initialise
             cuts = sorted({min(nkeys - 1, max(1, c // (2 * B * T) * (2 * B * T) or 2 * B)) for c in cuts})
-        desc = dict(offs=offs, a33=a33, a65=a65, endo=endo, start=hex(start), nkeys=nkeys, B=B, T=T, nwords=nw, mode=mode, cuts=cuts)
+        auto_geo = rnd.random() < 0.15  # library default: 2^21 lanes, half group chosen per call
+        desc = dict(auto_geo=auto_geo, offs=offs, a33=a33, a65=a65, endo=endo, start=hex(start), nkeys=nkeys, B=B, T=T, nwords=nw, mode=mode, cuts=cuts)
         d = Device(0, a33=a33, a65=a65, endo=endo, ord_offs=offs)
         got = []
         try:
-            d.set_geometry(B, T)
+            if not auto_geo:
+                d.set_geometry(B, T)
             d.set_bloom(words)
             at = 0
             for c in cuts + [nkeys]:
