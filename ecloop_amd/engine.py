@@ -233,7 +233,7 @@ class FoundRecord:
 class KeySearch:
     """ctx_t + cmd_add / cmd_mul for one GPU."""
 
-    def __init__(self, flt, device=0, a33=True, a65=False, endo=False, ord_offs=0, verify=True, launch_keys=1 << 30,
+    def __init__(self, flt, device=0, a33=True, a65=False, endo=False, ord_offs=0, verify=True, launch_keys=1 << 32,
                  half_group=0, max_lanes=0):
         if not (a33 or a65):
             a33 = True  # main.c:825-827
