@@ -25,7 +25,7 @@ FOUND_DTYPE = np.dtype([("key_offset", "<u8"), ("h160", "<u4", (5,)), ("endo", "
 assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 
 EXPORTS = [
-    "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_add_range",
+    "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
 ]
@@ -52,6 +52,7 @@ def load():
     lib.ecl_hip_close.restype = None
     lib.ecl_hip_set_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_set_list.argtypes = [P, C.c_void_p, C.c_uint64]
+    lib.ecl_hip_reserve.argtypes = [P, C.c_uint64, C.c_uint32]
     lib.ecl_hip_add_range.argtypes = [P, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_mul_batch.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_bloom_insert.argtypes = [P, C.c_void_p, C.c_uint64]
@@ -121,6 +122,10 @@ class Device:
         """sorted unique (n x 5) uint32 hash list for the on-device exact confirm; None / empty removes it"""
         H = np.zeros((0, 5), np.uint32) if hashes is None else np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)
         self._chk(self.lib.ecl_hip_set_list(self.h, H.ctypes.data if len(H) else None, len(H)))
+
+    def reserve(self, nkeys, cap=4096):
+        """allocate the device buffers of a later add_range(nkeys) now"""
+        self._chk(self.lib.ecl_hip_reserve(self.h, nkeys, cap))
 
     def bloom_insert(self, hashes):
         H = np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)

@@ -515,6 +515,57 @@ extern "C" int ecl_hip_get_geometry(ecl_hip* h, uint32_t* half_group, uint32_t* 
   return ECL_OK;
 }
 
+// Geometry of one call.  The table for half group h->B holds the tables of all smaller ones as prefixes.  A call too
+// short to give every one of the Tmax lanes a whole group takes a smaller half group (down to 256) instead of fewer
+// lanes: the walk only reaches its rate when the chip is oversubscribed with blocks in different phases (2^29 keys:
+// 11.5 Gkeys/s with 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion: 270 / 2B
+// multiplications per key).  Contiguous calls of one size keep one geometry, so they still continue the resident walk.
+static void call_geometry(const ecl_hip* h, u64 nkeys, u32& B, u32& nb, u32& T) {
+  B = h->B;
+  if (h->B_auto)
+    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+  const u64 group = 2ull * B, ngroups = (nkeys + group - 1) / group;
+  // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
+  // through a mostly masked last group
+  nb = (u32)((ngroups + h->Tmax - 1) / h->Tmax);
+  T = (u32)(((ngroups + nb - 1) / nb + 255) & ~255ull);
+  if (T > h->Tmax) T = h->Tmax;
+}
+// device buffers of a call with that geometry: lane centres and prefix-product chains
+static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
+  if (h->cxy_T < T) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_cxy) HIPCHK(h, hipFree(h->d_cxy));
+    h->d_cxy = nullptr, h->cxy_T = 0, h->walk_valid = false;
+    HIPCHK(h, hipMalloc(&h->d_cxy, (size_t)T * 4 * sizeof(uint4)));
+    h->cxy_T = T;
+  }
+  const size_t need = (size_t)T * B * 2;
+  if (h->scr_elems < need) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
+    if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
+    h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
+    HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
+    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(u32)));
+    h->scr_elems = need;
+  }
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
+  if (!h || nkeys == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = default_lanes(h)) != ECL_OK) return rc;
+  if ((rc = ensure_table(h)) != ECL_OK) return rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  u32 B, nb, T;
+  call_geometry(h, nkeys, B, nb, T);
+  return ensure_walk_buffers(h, B, T);
+}
+
 extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
   if (!h || !start || (!out && cap) || !nout) return ECL_E_ARG;
@@ -528,21 +579,10 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
 
-  // The table for half group h->B holds the tables of all smaller ones as prefixes.  A call too short to give every
-  // one of the Tmax lanes a whole group takes a smaller half group (down to 256) instead of fewer lanes: the walk only
-  // reaches its rate when the chip is oversubscribed with blocks in different phases (2^29 keys: 11.5 Gkeys/s with
-  // 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion: 270 / 2B multiplications
-  // per key).  Contiguous calls of one size keep one geometry, so they still continue the resident walk.
-  u32 B = h->B;
-  if (h->B_auto)
-    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+  u32 B, nb, T;
+  call_geometry(h, nkeys, B, nb, T);
   const u64 group = 2ull * B;
-  u64 ngroups = (nkeys + group - 1) / group;
-  // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
-  // through a mostly masked last group
-  u32 nb = (u32)((ngroups + h->Tmax - 1) / h->Tmax);
-  u32 T = (u32)(((ngroups + nb - 1) / nb + 255) & ~255ull);
-  if (T > h->Tmax) T = h->Tmax;
+  if ((rc = ensure_walk_buffers(h, B, T)) != ECL_OK) return rc;
 
   u256 k0 = sc_reduce(u256_from(start));
   const u256 s = sc_pow2(h->offs);
@@ -557,16 +597,6 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
       return ECL_E_RANGE;
     }
   }
-  size_t need = (size_t)T * B * 2;
-  if (h->scr_elems < need) {
-    if (h->d_scr) HIPCHK(h, hipFree(h->d_scr));
-    if (h->d_scr2) HIPCHK(h, hipFree(h->d_scr2));
-    h->d_scr = nullptr, h->d_scr2 = nullptr, h->scr_elems = 0;
-    HIPCHK(h, hipMalloc(&h->d_scr, need * sizeof(uint4)));
-    HIPCHK(h, hipMalloc(&h->d_scr2, (need / 2) * sizeof(u32)));
-    h->scr_elems = need;
-  }
-
   bool cont = h->walk_valid && h->walk_T == T && h->walk_B == B && u256_eq(h->walk_next, k0);
   if (!cont) {
     // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G
@@ -582,13 +612,6 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     HIPCHK(h, hipMemcpyAsync(h->d_auxk, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_mul_g, dim3(1), dim3(64), 0, h->stream, h->d_auxk, h->d_aux, (u8*)nullptr, 34u);
     HIPCHK(h, hipGetLastError());
-    if (h->cxy_T < T) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      if (h->d_cxy) HIPCHK(h, hipFree(h->d_cxy));
-      h->d_cxy = nullptr, h->cxy_T = 0;
-      HIPCHK(h, hipMalloc(&h->d_cxy, (size_t)T * 4 * sizeof(uint4)));
-      h->cxy_T = T;
-    }
     if (B >= 8)  // the chain scratch (T * B * 36 bytes) holds the 144 bytes per lane the batched set-up parks
       hipLaunchKernelGGL(k_init_centres_batched, dim3((T / INIT_R + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32,
                          h->d_cxy, T, (u32*)h->d_scr);

@@ -94,6 +94,11 @@ int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
 
+/* Optional: allocate now what a later ecl_hip_add_range of `nkeys` keys with record capacity `cap` will need (table,
+   lane centres, prefix-product chains, record buffer), so that the first call does not pay for it.  The reference has
+   no counterpart (its per-thread buffers live on the stack, main.c:350-352). */
+int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
+
 /* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
                       uint32_t *nout);

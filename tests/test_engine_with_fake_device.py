@@ -34,6 +34,9 @@ class FakeDevice:
     def set_list(self, hashes):
         self.list = None if hashes is None else {tuple(int(w) for w in h) for h in hashes}
 
+    def reserve(self, nkeys, cap=4096):
+        pass
+
     def set_geometry(self, half_group=0, max_lanes=0):
         self.half = half_group or self.half
         self.lanes = max_lanes or self.lanes
