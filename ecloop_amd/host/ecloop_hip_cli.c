@@ -58,6 +58,11 @@ static u64 sc_addraw(sc *r, const sc *a, const sc *b) {
   for (int i = 0; i < 4; ++i) c += (u128)a->w[i] + b->w[i], r->w[i] = (u64)c, c >>= 64;
   return (u64)c;
 }
+/* 256-bit logical shift right by one */
+static sc sc_shr1(sc a) {
+  for (int i = 0; i < 4; ++i) a.w[i] = (a.w[i] >> 1) | (i < 3 ? a.w[i + 1] << 63 : 0);
+  return a;
+}
 static u64 sc_subraw(sc *r, const sc *a, const sc *b) {
   u64 br = 0;
   for (int i = 0; i < 4; ++i) {
@@ -989,6 +994,19 @@ int main(int argc, const char **argv) {
     int rc = ecl_hip_open(&ctx.dev[g], g % real, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
     if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx.dev[g], ctx.blf.bits, ctx.blf.size);
     if (rc == ECL_OK && ctx.list) rc = ecl_hip_set_list(ctx.dev[g], (const uint32_t(*)[5])ctx.list, ctx.list_count);
+    if (rc == ECL_OK && ctx.cmd != CMD_MUL) {
+      /* walk buffers of this device's share of the scan, before the clock of the status line starts */
+      u64 share = 1ull << 32;
+      if (ctx.cmd == CMD_RND) {
+        share = (ctx.ord_size < 32 ? 1ull << (ctx.ord_size < 21 ? 21 : ctx.ord_size) : 1ull << 32) / (u64)ctx.ngpus;
+      } else {
+        sc span;
+        sc_subraw(&span, &ctx.range_e, &ctx.range_s);
+        for (u32 i = 0; i < ctx.ord_offs && i < 256; ++i) span = sc_shr1(span);
+        if (!(span.w[1] | span.w[2] | span.w[3]) && span.w[0] / (u64)ctx.ngpus + 4096 < share) share = span.w[0] / (u64)ctx.ngpus + 4096;
+      }
+      rc = ecl_hip_reserve(ctx.dev[g], share ? share : 1, 4096);
+    }
     if (rc != ECL_OK) die_ecl(&ctx, g, rc, "open");
   }
   printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", ctx.ngpus, ctx.a33, ctx.a65, ctx.endo);
