@@ -27,7 +27,7 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
-    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom",
+    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod",
 ]
 
 _lib = None
@@ -70,6 +70,7 @@ def load():
     lib.ecl_hip_diag_mulg.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.ecl_hip_diag_hash160.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.ecl_hip_diag_bloom.argtypes = [P, C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ecl_hip_diag_bloom_mod.argtypes = [P, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
     _lib = lib
     return lib
 
@@ -200,3 +201,9 @@ class Device:
         hit = np.zeros(len(H), dtype=np.uint8)
         self._chk(self.lib.ecl_hip_diag_bloom(self.h, H.ctypes.data, hit.ctypes.data, len(H)))
         return hit
+
+    def diag_bloom_mod(self, nwords, xs):
+        X = np.ascontiguousarray(xs, dtype=np.uint64)
+        R = np.zeros_like(X)
+        self._chk(self.lib.ecl_hip_diag_bloom_mod(self.h, nwords, X.ctypes.data, R.ctypes.data, len(X)))
+        return R

@@ -194,6 +194,12 @@ __global__ void k_diag_bloom(bloom_t b, const u32* h160, u8* hit, u32 n) {
   hit[i] = bloom_has(b, h) ? 1 : 0;
 }
 
+// bloom_mod alone, for any filter size (no bit array needed): pins the reciprocal modulo of both width classes
+__global__ void k_diag_bloom_mod(bloom_t b, const u64* x, u64* r, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) r[i] = bloom_mod(b, x[i]);
+}
+
 __global__ void k_bloom_insert(bloom_t b, u64* bits, const u32* h160, u64 n) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -531,6 +537,16 @@ static void call_geometry(const ecl_hip* h, u64 nkeys, u32& B, u32& nb, u32& T) 
   T = (u32)(((ngroups + nb - 1) / nb + 255) & ~255ull);
   if (T > h->Tmax) T = h->Tmax;
 }
+// what call_geometry can represent: the group count must not wrap and groups per lane must fit 32 bits
+// (a caller-set geometry of 2 x 256 lanes reaches that at 2^42 keys; the default one never does below 2^63)
+static bool nkeys_ok(const ecl_hip* h, u64 nkeys) {
+  if (nkeys > (1ull << 63)) return false;
+  u32 B = h->B;
+  if (h->B_auto)
+    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+  const u64 ngroups = (nkeys + 2ull * B - 1) / (2ull * B);
+  return (ngroups + h->Tmax - 1) / h->Tmax < (1ull << 32);
+}
 // device buffers of a call with that geometry: lane centres and prefix-product chains
 static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
   if (h->cxy_T < T) {
@@ -559,6 +575,7 @@ extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
+  if (!nkeys_ok(h, nkeys)) return ECL_E_ARG;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
   u32 B, nb, T;
@@ -575,6 +592,10 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
+  if (!nkeys_ok(h, nkeys)) {
+    h->err = "nkeys too large for one call with this geometry";
+    return ECL_E_ARG;
+  }
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
@@ -833,6 +854,20 @@ extern "C" int ecl_hip_diag_bloom(ecl_hip* h, const uint32_t (*h160)[5], uint8_t
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(hit, dhit.p, n, hipMemcpyDeviceToHost));
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_diag_bloom_mod(ecl_hip* h, uint64_t nwords, const uint64_t* x, uint64_t* r, uint32_t n) {
+  if (!h || !x || !r || n == 0 || nwords == 0 || nwords >= (1ull << 58)) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  dbuf<u64> dx, dr;
+  HIPCHK(h, hipMalloc(&dx.p, (size_t)n * 8));
+  HIPCHK(h, hipMalloc(&dr.p, (size_t)n * 8));
+  HIPCHK(h, hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_diag_bloom_mod, dim3((n + 63) / 64), dim3(64), 0, h->stream, bloom_make(nullptr, nwords), dx.p, dr.p, n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(r, dr.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return ECL_OK;
 }
 

@@ -62,4 +62,5 @@ int dh_bloom_has(const uint64_t* bits, uint64_t nwords, const uint32_t h[5]) {
   bloom_t b = bloom_make(bits, nwords);
   return bloom_has(b, h) ? 1 : 0;
 }
+uint64_t dh_bloom_mod(uint64_t nwords, uint64_t x) { return bloom_mod(bloom_make(nullptr, nwords), x); }
 }

@@ -65,7 +65,9 @@ typedef struct ecl_found {
 
 int ecl_hip_device_count(void);
 
-/* Create a context on `device`. ord_offs: stride between consecutive keys is 2^ord_offs (0..255, main.c:221-222). */
+/* Create a context on `device`. ord_offs: stride between consecutive keys is 2^ord_offs (0..255, main.c:221-222).
+   On ECL_E_ARG / ECL_E_NODEV *out is untouched.  On any later failure (ECL_E_HIP, ECL_E_SELFTEST) *out holds a context
+   that can only be asked for ecl_hip_last_error() and must be given to ecl_hip_close(). */
 int ecl_hip_open(ecl_hip **out, int device, uint32_t flags, uint32_t ord_offs);
 void ecl_hip_close(ecl_hip *h);
 
@@ -90,7 +92,8 @@ int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
    selected at open) and report every bloom hit.  start: 256-bit scalar, 4 little-endian u64 limbs, as `fe`.
    Exactly these keys are tested - the caller reproduces the reference's job rounding (main.c:442,368).
    Consecutive calls whose `start` continues the previous range reuse the on-device walk state.
-   Returns ECL_OK, ECL_E_OVERFLOW (see above) or an error. */
+   Returns ECL_OK, ECL_E_OVERFLOW (see above) or an error; ECL_E_ARG for an nkeys the geometry cannot walk in one call
+   (more than 2^63, or more than 2^32 groups per lane - only reachable with a tiny caller-set geometry). */
 int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
 
@@ -136,6 +139,9 @@ int ecl_hip_diag_hash160(ecl_hip *h, const uint64_t (*x)[4], const uint64_t (*y)
                          uint32_t (*h65)[5], uint32_t n);
 /* bloom probe of n hashes against the resident filter */
 int ecl_hip_diag_bloom(ecl_hip *h, const uint32_t (*h160)[5], uint8_t *hit, uint32_t n);
+/* the probe's word index r[i] = x[i] mod nwords (the `% (blf->size * 64)` of utils.c:286-288 on the word index) as the
+   device computes it, for any filter size 0 < nwords < 2^58 and x < 2^58; no filter needs to be resident */
+int ecl_hip_diag_bloom_mod(ecl_hip *h, uint64_t nwords, const uint64_t *x, uint64_t *r, uint32_t n);
 
 #ifdef __cplusplus
 }

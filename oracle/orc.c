@@ -551,6 +551,22 @@ int orc_blf_has(const uint64_t *bits, uint64_t size, const uint32_t h[5]) {
     if (!(bits[idx[i] % (size * 64) / 64] >> (idx[i] % 64) & 1)) return 0;
   return 1;
 }
+/* bulk forms for the tests (plain loops over the two functions above).  orc_blf_gen_many is the insert loop of
+   blf-gen (utils.c:455-470): a hash already reported by blf_has is skipped and not counted. */
+void orc_blf_add_many(uint64_t *bits, uint64_t size, const uint32_t *h, uint64_t n) {
+  for (u64 i = 0; i < n; ++i) orc_blf_add(bits, size, h + i * 5);
+}
+void orc_blf_has_many(const uint64_t *bits, uint64_t size, const uint32_t *h, uint64_t n, uint8_t *hit) {
+  for (u64 i = 0; i < n; ++i) hit[i] = (uint8_t)orc_blf_has(bits, size, h + i * 5);
+}
+uint64_t orc_blf_gen_many(uint64_t *bits, uint64_t size, const uint32_t *h, uint64_t n) {
+  u64 count = 0;
+  for (u64 i = 0; i < n; ++i) {
+    if (orc_blf_has(bits, size, h + i * 5)) continue;
+    orc_blf_add(bits, size, h + i * 5), count++;
+  }
+  return count;
+}
 /* utils.c:421-427: m = n*ln(1e-9)/ln(1/2^ln2) bits, size = ceil(m/64) words */
 uint64_t orc_blf_gen_size(uint64_t n) {
   double p = 1.0 / (double)1000000000ULL;

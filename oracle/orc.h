@@ -62,6 +62,9 @@ void orc_hash160_65(uint32_t h[5], const orc_fe x, const orc_fe y);
 /* --- bloom filter (utils.c:274-326) --- */
 void orc_blf_add(uint64_t *bits, uint64_t size_words, const uint32_t h[5]);
 int orc_blf_has(const uint64_t *bits, uint64_t size_words, const uint32_t h[5]);
+void orc_blf_add_many(uint64_t *bits, uint64_t size_words, const uint32_t *h, uint64_t n);
+void orc_blf_has_many(const uint64_t *bits, uint64_t size_words, const uint32_t *h, uint64_t n, uint8_t *hit);
+uint64_t orc_blf_gen_many(uint64_t *bits, uint64_t size_words, const uint32_t *h, uint64_t n); /* utils.c:455-470 */
 uint64_t orc_blf_gen_size(uint64_t n); /* utils.c:421-427 size formula (words) */
 
 /* --- filter = bloom + optional sorted list (main.c:71-131, 205-217) --- */

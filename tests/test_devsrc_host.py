@@ -78,3 +78,27 @@ def test_bloom_probe(D, nw, mode):
         hits += a
     if mode == "ones":
         assert hits == 5000
+
+
+MOD_SIZES = [1, 2, 3, 65539, (1 << 24) - 1, 1 << 24, (1 << 24) + 3, 92_175_407, 737_403_255, (1 << 31) - 1, 1 << 31,
+             (1 << 31) + 12345, (1 << 33) + 7, (1 << 40) - 87, (1 << 57) + 1, (1 << 58) - 1]
+
+
+def mod_inputs(nw, n=4000, seed=17):
+    """word indices (idx >> 6 < 2^58) that stress the reciprocal: random, multiples of nw +- 1, the extremes"""
+    rnd = random.Random(seed ^ nw)
+    top = (1 << 58) - 1
+    xs = [0, 1, nw - 1, nw, nw + 1, top, top - 1, top // nw * nw, max(top // nw * nw - 1, 0)]
+    xs += [rnd.getrandbits(58) for _ in range(n)]
+    xs += [min(rnd.randrange(1, top // nw + 1) * nw + d, top) for _ in range(n // 4) for d in (-1, 0, 1)]
+    return [x for x in xs if 0 <= x <= top]
+
+
+@pytest.mark.parametrize("nw", MOD_SIZES)
+def test_bloom_mod_all_width_classes(D, nw):
+    """bloom_mod (the `% size` of utils.c:286-288 on the word index) against Python's %, including the 64-bit branch
+    that serves filters of 2^31 words (16 GB) and more — no such filter needs to exist for this"""
+    D.dh_bloom_mod.restype = C.c_uint64
+    D.dh_bloom_mod.argtypes = [C.c_uint64, C.c_uint64]
+    for x in mod_inputs(nw):
+        assert D.dh_bloom_mod(nw, x) == x % nw, (nw, x)

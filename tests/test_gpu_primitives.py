@@ -118,6 +118,14 @@ def test_c_abi_error_codes():
         assert lib.ecl_hip_add_range(h, zero, 2048, out.ctypes.data, 16, C.byref(n)) == -6                     # ECL_E_RANGE
         assert b"private key 0" in lib.ecl_hip_last_error(h)
         assert lib.ecl_hip_set_geometry(h, 1, 0) == -1 and lib.ecl_hip_set_geometry(h, 1 << 17, 0) == -1
+        # key counts the walk geometry cannot represent are refused, not walked into a division by zero
+        for nk in (2**64 - 1, 2**63 + 1):
+            assert lib.ecl_hip_add_range(h, start, nk, out.ctypes.data, 16, C.byref(n)) == -1
+            assert lib.ecl_hip_reserve(h, nk, 16) == -1
+        assert lib.ecl_hip_set_geometry(h, 2, 256) == 0
+        assert lib.ecl_hip_add_range(h, start, 1 << 42, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_reserve(h, 1 << 42, 16) == -1
+        assert lib.ecl_hip_add_range(h, start, 4096, None, 0, C.byref(n)) == -4 and n.value == 4096
         for rc in range(-7, 1):
             assert lib.ecl_hip_strerror(rc)
     finally:
