@@ -3,19 +3,28 @@
 
     python bench.py [--gpus N --steps K --warmup W]              (N>1: launched by torch.distributed.run)
 
-One step = one pass of the hot path over a contiguous range of 2^32 private keys (per GPU) against a `.blf`-format
-bloom filter resident in HBM: batch affine additions, SHA-256 -> RIPEMD-160 of every compressed public key, bloom
-probe, hits gathered on the host.  Inputs are synthetic and already in HBM when the timed region starts: the
-filter holds 10^7 seeded pseudo-random hash160 values plus 16 planted keys of the scanned range (so the found list
-is not empty and is checked).  The keyspace is range-partitioned: rank r scans [A + r*2^32, A + (r+1)*2^32); there
-is no collective on the data path, only the timing barrier (weak scaling).
+One step = one pass of the hot path over ONE contiguous range of 2^32 private keys from 0x1_0000_0000 against a
+`.blf`-format bloom filter resident in HBM: batch affine additions, SHA-256 -> RIPEMD-160 of every compressed public
+key, bloom probe, hits gathered on the host.  With N GPUs the range is cut into N contiguous shards, one per rank
+(north_star: "a 2^32 contiguous range at 1, 2, 4 and 8 MI355X") - strong scaling, no collective on the data path, only
+the timing barrier.  `weak_scaling` in the same line is a second, separately timed leg where every rank scans its own
+2^32 keys (`--scaling weak` makes that leg the headline instead).  Inputs are synthetic and already in HBM when the
+timed region starts: the filter holds 10^7 seeded pseudo-random hash160 values plus 16 planted keys per 2^32-key range
+(so the found list is not empty and is checked: a missing planted key or a found list that differs from the reference
+binary's on the CPU sample aborts the run).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the fused kernel against the integer-VALU issue peak measured
-by ecloop_amd/csrc/tools/ubench.hip; `cpu_baseline` is the unmodified reference binary
-(oracle/_ref, built from /root/reference by oracle/Makefile) timed on this host's cores over a bounded sample of
-the same range and filter, or the oracle port if the binary is not there.
+Prints ONE JSON line (rank 0).  `roofline`: the kernel is integer-VALU issue bound; `achieved` = VALU lane-operations
+per key (rocprofv3 SQ_INSTS_VALU of THIS build, loaded from the tracked profile named in the line) x keys per launch
+/ the kernel's HIP-event time measured in this process.  Nothing in it is a constant typed into this file: every field
+is measured here or loaded from profiles/<tag>_roofline.json (tools/collect_profiles.sh), and `profile.matches_build`
+says whether that profile was taken on the sources being run.  `cpu_baseline` is the unmodified reference binary
+(oracle/_ref, built from /root/reference by oracle/Makefile) timed on this host's cores over a bounded sample of the
+same range and filter, or the oracle port if the binary is not there.
+
+    python bench.py --cmd mul      non-headline: the `mul` path (2^24 seeded scalars per step through ecl_hip_mul_batch)
 """
 import argparse
+import glob
 import json
 import os
 import re
@@ -32,24 +41,13 @@ sys.path.insert(0, ROOT)
 RANGE_A = 0x100000000  # configs[1] / SURVEY §8d: add -r 100000000:1ffffffff
 FILTER_N = 10_000_000
 PLANTED = 16
-# Work per addr33 key, priced as SURVEY.md §8d prescribes: the static VALU instruction count per key from the gfx950
-# assembly (tools/isa_mix.py over the hot blocks, weighted by trip count: 3042, plus the amortised inversion and
-# candidate-ring drains; total taken from the PMC count SQ_INSTS_VALU: 3127 per key) times the issue cost of each class measured by the dependency-free microbenchmark (profiles/ubench_r01.txt,
-# SIMD-cycles per wave-instruction at the nominal clock):
-#   422 v_mad_u64_u32 x 4.61 + 606 double-rate VOP2 (add/sub/and/or/xor/mov) x 2.55 + 2099 other VALU x 4.23
-#   = 12 370 SIMD-cycles per 64 keys = 3092 lane-cycles per key (16 lanes per SIMD-cycle).
-# (SURVEY's estimate before any code existed: 313 IMAD + 350 ALU + 2570 ALU = 3233 ops, ~4.2 k lane-cycles.)
-VALU_PER_KEY = {"mad64": 422, "fast_vop2": 606, "other": 2099}
-ISSUE_CYCLES = {"mad64": 4.61, "fast_vop2": 2.55, "other": 4.23}
-OPS_PER_KEY = sum(VALU_PER_KEY.values())
-LANE_CYCLES_PER_KEY = sum(VALU_PER_KEY[k] * ISSUE_CYCLES[k] for k in VALU_PER_KEY) / 4.0
-# peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-cycles/s (one 64-wide VALU instruction per SIMD per 4 clocks)
-PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-# HBM-side bytes per key from the PMC passes (profiles/r01_pmc_traffic.txt: FETCH_SIZE 117.6 B + WRITE_SIZE 18.0 B per key:
-# 1.8 64-byte bloom sectors per key + the 36 B / 2 keys prefix-product chain each way + spills). Not the bound: 1.5 TB/s.
-TRAFFIC_BYTES_PER_KEY = 135.6
+# hardware peaks (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz, HBM3E 8 TB/s).  A wave64 VALU instruction occupies
+# its SIMD for 4 clocks (16 lanes per clock); the add/sub/and/or/xor/mov/bitop3 class issues in ~2 in long runs
+# (32 lanes per clock: the guide's "v_fma_f32 2 cyc").  Measured per opcode by ecloop_amd/csrc/tools/ubench.hip.
+PEAK_4CYCLE = 256 * 4 * 16 * 2.4e9 / 1e12
+PEAK_2CYCLE = 2 * PEAK_4CYCLE
 HBM_PEAK_GBS = 8000.0
-VALU_BUSY_PCT = 99.0  # rocprofv3 --pmc VALUBusy on the 2^32-key launch (profiles/r01_pmc_valu.txt)
+ALGO_BYTES_PER_KEY = 18 + 18 + 1.59 * 8  # chain element (36 B) written + read per two keys; 1.59 probes x 8 B
 
 
 def splitmix_hashes(n, seed):
@@ -63,8 +61,13 @@ def splitmix_hashes(n, seed):
     return np.ascontiguousarray(w)
 
 
-def build_filter(dev, start, nkeys, filter_n=FILTER_N):
-    """filter_n random entries + PLANTED keys of [start, start+nkeys) -> bloom words resident on `dev`.
+def planted_offsets(nkeys):
+    return [(nkeys // PLANTED) * i + 12345 * (i + 1) % 4096 for i in range(PLANTED)]
+
+
+def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1):
+    """filter_n random entries + PLANTED keys in each of the `ranges` consecutive nkeys-key ranges from `start` -> bloom
+    words resident on `dev` (identical on every rank: one .blf replicated per GPU).
     Above 5*10^7 entries (non-headline experiments, e.g. the ~6 GB filter of configs[2]) the bit array is filled with
     random words of the design density 0.375 instead of inserting that many hashes."""
     from ecloop_amd.engine import blf_size_words
@@ -81,8 +84,8 @@ def build_filter(dev, start, nkeys, filter_n=FILTER_N):
     else:
         dev.set_bloom(np.zeros(size, dtype=np.uint64))
         dev.bloom_insert(splitmix_hashes(filter_n, 2025))
-    offs = [(nkeys // PLANTED) * i + 12345 * (i + 1) % 4096 for i in range(PLANTED)]
-    xs, ys, ok = dev.diag_mulg([start + o for o in offs])
+    offs = planted_offsets(nkeys)
+    xs, ys, ok = dev.diag_mulg([start + r * nkeys + o for r in range(ranges) for o in offs])
     h33, h65 = dev.diag_hash160(xs, ys)
     dev.bloom_insert(h33)
     dev.bloom_insert(h65)
@@ -147,20 +150,160 @@ def cpu_baseline(words, sample_keys_log2_max=33):
             "sample": f"oracle/orc.c add over 2^{log2n} keys, {threads} threads ({dt:.1f}s)"}, (log2n, lines)
 
 
+# ----------------------------------------------------------------------------------------------- roofline inputs
+
+
+def load_profile(kind="roofline"):
+    """the newest tracked profiles/r<NN>_<kind>.json (written by tools/collect_profiles.sh on the GPU box)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % kind)))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except Exception as e:
+        sys.stderr.write(f"[bench] cannot read {files[-1]}: {e}\n")
+        return None, None
+
+
+def static_fingerprint(kernel=None):
+    """instruction mix of the library being timed, from the assembly the build kept beside it (tools/isa_mix.py)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_mix
+        a = isa_mix.analyse(kernel=kernel) if kernel else isa_mix.analyse()
+        return a.get("fingerprint"), a.get("per_key_static")
+    except Exception as e:
+        sys.stderr.write(f"[bench] static instruction mix unavailable: {e}\n")
+        return None, None
+
+
+def add_roofline(ms_launch, keys_per_launch):
+    from ecloop_amd.build import source_sha256
+    prof, path = load_profile()
+    fp, static = static_fingerprint()
+    keys_s = keys_per_launch / (ms_launch * 1e-3) if ms_launch > 0 else 0.0
+    r = {"bound": "valu-int32", "kernel": "k_add<addr33>", "unit": "T lane-ops/s", "peak": round(PEAK_4CYCLE, 2),
+         "peak_definition": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz: one wave64 VALU instruction per SIMD per 4 clocks (profiles/ubench_r02.txt: "
+                            "rotates, shifts, v_add3, v_perm, multiplies, carries >= 4.1 cycles; only add/sub/and/or/xor/mov/bitop3 reach ~2.3-2.5 in long runs)",
+         "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch), "kernel_mkeys_s": round(keys_s / 1e6, 2),
+         "static": fp}
+    if prof is None:
+        r.update({"achieved": None, "frac": None, "traffic": None, "profile": None})
+        return r
+    d, t = prof.get("derived", {}), prof.get("traffic", {})
+    ops = d.get("valu_lane_ops_per_key")
+    matches = prof.get("source_sha256") == source_sha256()
+    r["profile"] = {"file": path, "source_sha256": prof.get("source_sha256", "")[:16], "matches_build": matches,
+                    "fingerprint_matches": (fp == prof.get("fingerprint")) if fp else None,
+                    "profiled_launch_ms": prof.get("profiled_launch_ms"), "clock_ghz": d.get("clock_ghz"),
+                    "valu_busy_pct": d.get("valu_busy_pct"), "simd_cycles_per_valu_instr": d.get("simd_cycles_per_valu_instr")}
+    if ops:
+        ach = ops * keys_s / 1e12
+        r.update({"achieved": round(ach, 3), "frac": round(ach / PEAK_4CYCLE, 4), "valu_lane_ops_per_key": round(ops, 1),
+                  "frac_vs_dual_rate_peak": round(ach / PEAK_2CYCLE, 4), "dual_rate_peak": round(PEAK_2CYCLE, 2)})
+        # ceiling of THIS instruction mix: class shares from the assembly, best-case cycles per class from the microbenchmark
+        ub = (prof.get("ubench_cycles_per_wave_instr") or {}).get("waves_per_simd_8") or {}
+        c_fast, c_slow, c_mad = ub.get("v_add_u32 (e32)"), ub.get("v_alignbit_b32"), ub.get("v_mad_u64_u32")
+        cal = ub.get("cal: v_bitop3_b32 only")
+        if static and c_fast and c_slow and c_mad:
+            tot = static["valu"]
+            sh = {k: static[k] / tot for k in ("mad64", "fast", "other")}
+            cyc = sh["mad64"] * c_mad + sh["fast"] * min(c_fast, cal["cycles"] if cal else c_fast) + sh["other"] * c_slow
+            ceil_keys = PEAK_4CYCLE * 1e12 * 4.0 / (ops * cyc)
+            r["mix_ceiling"] = {"class_share": {k: round(v, 3) for k, v in sh.items()}, "cycles_per_class": {"mad64": c_mad, "fast": c_fast, "other": c_slow},
+                                "mean_cycles_per_instr": round(cyc, 3), "ceiling_mkeys_s": round(ceil_keys / 1e6, 1),
+                                "frac": round(keys_s / ceil_keys, 4),
+                                "note": "every double-rate opcode priced at its long-run rate; in the hash they occur singly"}
+    if t.get("bytes_per_key_corrected"):
+        r["traffic"] = round(t["bytes_per_key_corrected"] * keys_per_launch)
+        r["traffic_source"] = f"{path}: FETCH_SIZE/WRITE_SIZE passes, corrected with the known-byte-count calibration in the same file"
+        r["hbm"] = {"achieved_gbs": round(ALGO_BYTES_PER_KEY * keys_s / 1e9, 1), "peak_gbs": HBM_PEAK_GBS,
+                    "frac": round(ALGO_BYTES_PER_KEY * keys_s / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_key": round(ALGO_BYTES_PER_KEY, 1),
+                    "measured_bytes_per_key": round(t["bytes_per_key_corrected"], 1)}
+    else:
+        r["traffic"] = None
+    if not matches:
+        r["profile"]["note"] = "STALE: the counters in this profile were taken on other sources; rerun tools/collect_profiles.sh"
+    return r
+
+
+# ----------------------------------------------------------------------------------------------- mul (non-headline)
+
+
+def bench_mul(args, rank, world, local, dist, barrier):
+    import torch
+    from ecloop_amd.engine import Filter, KeySearch
+    n = 1 << args.mul_log2
+    ks = KeySearch(Filter(np.zeros(64, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr, verify=False)
+    rng = np.random.default_rng(1234 + rank)
+    scal = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    lib, h = ks.dev.lib, ks.dev.h
+    import ctypes as C
+    out = np.zeros(64, dtype=np.dtype([("b", "u1", (32,))]))
+    cnt = C.c_uint32()
+
+    def step():
+        rc = lib.ecl_hip_mul_batch(h, scal.ctypes.data, n, out.ctypes.data, 64, C.byref(cnt))
+        if rc not in (0, -4):
+            raise SystemExit(f"[bench] mul_batch failed: {rc}")
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ks.dev.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms, calls, nsc = ks.dev.mul_timing()
+    if rank != 0:
+        return
+    hashes = len(args.addr)
+    prof, path = load_profile("mul")
+    res = {"metric": f"M scalars/sec (mul -a {args.addr})", "value": round(n * world * args.steps / dt / 1e6, 2), "unit": "Mscalars/s", "n_gpus": world,
+           "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": f"mul -a {args.addr}: 2^{args.mul_log2} seeded 256-bit scalars per GPU per step from HOST memory through "
+                                  "ecl_hip_mul_batch (copies overlapped with the kernel), empty filter", "hashes_per_scalar": hashes},
+           "roofline": {"bound": "valu-int32", "kernel": "k_mul_check", "ms_per_call_on_stream": round(ms / max(calls, 1), 3),
+                        "device_mscalars_s": round(nsc / (ms * 1e-3) / 1e6, 2) if ms else None,
+                        "pcie_gbs": round(nsc * 32 / (ms * 1e-3) / 1e9, 2) if ms else None}}
+    if prof and prof.get("derived", {}).get("valu_lane_ops_per_scalar"):
+        ops = prof["derived"]["valu_lane_ops_per_scalar"]
+        ach = ops * nsc / (ms * 1e-3) / 1e12
+        res["roofline"].update({"achieved": round(ach, 3), "peak": round(PEAK_4CYCLE, 2), "unit": "T lane-ops/s", "frac": round(ach / PEAK_4CYCLE, 4),
+                                "valu_lane_ops_per_scalar": round(ops, 1), "profile": path})
+    print(json.dumps(res))
+
+
+# ----------------------------------------------------------------------------------------------- main
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--keys-log2", type=int, default=32, help="keys per GPU per step (default 2^32 = the named config)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = ONE 2^keys-log2 range cut into N shards (default, the named config); weak = 2^keys-log2 keys per GPU")
+    ap.add_argument("--keys-log2", type=int, default=32, help="keys per step (strong) / per GPU per step (weak); default 2^32 = the named config")
     ap.add_argument("--launch-log2", type=int, default=32, help="largest number of keys given to one device call")
     ap.add_argument("--half-group", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-second-leg", action="store_true", help="N>1: skip the other scaling mode's leg")
     ap.add_argument("--addr", default="c", choices=["c", "u", "cu"], help="non-headline variants: -a u / -a cu")
     ap.add_argument("--endo", action="store_true", help="non-headline variant: -endo (6 images per key)")
     ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
+    ap.add_argument("--cmd", default="add", choices=["add", "mul"], help="mul: the non-headline `mul` path")
+    ap.add_argument("--mul-log2", type=int, default=24)
     args = ap.parse_args()
+    t_process = time.perf_counter()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already set on the boxes)
     rank = int(os.environ.get("RANK", "0"))
@@ -188,18 +331,6 @@ def main():
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing
     if dist is not None:
         dist.barrier()
-    from ecloop_amd.engine import Filter, KeySearch, calc_priv
-    nkeys = 1 << args.keys_log2
-    start = RANGE_A + rank * nkeys
-
-    # --- inputs -> HBM (untimed)
-    headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
-    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr,
-                   endo=args.endo, verify=True,
-                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
-    size, planted_offs, planted_h = build_filter(ks.dev, start, nkeys, args.filter_n)
-    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
-    ks.dev.reserve(min(nkeys, 1 << args.launch_log2))  # walk buffers allocated with the inputs, outside the timed region
 
     def barrier():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -207,74 +338,110 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
-        ks.found.clear()
-        ks.add_keys(start, nkeys)
+    if args.cmd == "mul":
+        bench_mul(args, rank, world, local, dist, barrier)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    for _ in range(args.warmup):
-        step()
-    ks.dev.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from ecloop_amd.engine import Filter, KeySearch, calc_priv, shard
+    nkeys = 1 << args.keys_log2
+    # per-rank scan of each leg: strong = shard `rank` of the one range, weak = the rank's own range
+    legs = {"strong": (RANGE_A + shard(nkeys, rank, world)[0], shard(nkeys, rank, world)[1]),
+            "weak": (RANGE_A + rank * nkeys, nkeys)}
+    order = [args.scaling] + ([m for m in ("strong", "weak") if m != args.scaling] if world > 1 and not args.no_second_leg else [])
 
-    # --- correctness of what was just timed: every planted key is in the found list with the right scalar
-    found_pks = {r.pk for r in ks.found}
-    missing = [o for o in planted_offs if calc_priv(start, 1, o, 0) not in found_pks]
-    if missing:
-        raise SystemExit(f"[bench] rank {rank}: planted keys not found: {missing}")
-    kernel_ms, launches, kkeys = ks.dev.timing()
+    # --- inputs -> HBM (untimed)
+    headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
+    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr,
+                   endo=args.endo, verify=True,
+                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
+    size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.filter_n, ranges=world)
+    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
+    for m in order:  # walk buffers allocated with the inputs, outside the timed region
+        ks.dev.reserve(min(legs[m][1], 1 << args.launch_log2))
+    t_setup = time.perf_counter() - t_process
 
-    ok_flag = torch.tensor([1], device="cpu" if share else "cuda") if dist is not None else None
-    if dist is not None:
+    def run_leg(mode, steps, warmup):
+        start, cnt = legs[mode]
+
+        def step():
+            ks.found.clear()
+            ks.add_keys(start, cnt)
+
+        for _ in range(warmup):
+            step()
+        ks.dev.reset_timing()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # correctness of what was just timed: every planted key inside this rank's scan is in the found list
+        found_pks = {r.pk for r in ks.found}
+        mine = [RANGE_A + r * nkeys + o for r in range(world) for o in planted_offs]
+        mine = [k for k in mine if start <= k < start + cnt]
+        missing = [hex(k) for k in mine if calc_priv(k, 1, 0, 0) not in found_pks]
+        if missing:
+            raise SystemExit(f"[bench] rank {rank} ({mode}): planted keys not found: {missing}")
+        kernel_ms, launches, kkeys = ks.dev.timing()
+        setup_ms, setups = ks.dev.setup_timing()
+        total = (nkeys if mode == "strong" else nkeys * world) * steps
+        return {"dt": dt, "value": total / dt / 1e6, "ms_per_step": dt / steps * 1e3, "kernel_ms": kernel_ms, "launches": launches,
+                "kkeys": kkeys, "setup_ms": setup_ms, "setups": setups, "planted_checked": len(mine), "found": len(ks.found),
+                "found_lines": sorted(r.line() for r in ks.found)}
+
+    out = {order[0]: run_leg(order[0], args.steps, args.warmup)}
+    for m in order[1:]:
+        out[m] = run_leg(m, min(args.steps, 5), 1)
+    if dist is not None:  # a rank that aborted above never gets here: the others would hang in the barrier, not report
+        ok_flag = torch.tensor([1], device="cpu" if share else "cuda")
         dist.all_reduce(ok_flag)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_keys = nkeys * world * args.steps
-    value = total_keys / dt / 1e6
-    ms_launch = kernel_ms / max(launches, 1)
-    keys_per_launch = kkeys / max(launches, 1)
-    achieved = keys_per_launch * LANE_CYCLES_PER_KEY / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
+    main_leg = out[order[0]]
+    ms_launch = main_leg["kernel_ms"] / max(main_leg["launches"], 1)
+    keys_per_launch = main_leg["kkeys"] / max(main_leg["launches"], 1)
+    per_gpu = legs[order[0]][1]
+    what = (f"ONE range of 2^{args.keys_log2} contiguous keys from 0x{RANGE_A:x} cut into {world} contiguous shard(s)" if order[0] == "strong"
+            else f"2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}")
     res = {
-        "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})", "value": round(value, 2), "unit": "Mkeys/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"add addr33, 2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}, "
-                               f".blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
-                   "keys_per_gpu_per_step": nkeys, "parallelism": f"range-sharded x{world}, no collective",
-                   "found_per_step": len(ks.found), "planted_found": PLANTED - len(missing)},
-        "roofline": {"bound": "valu-int32", "achieved": round(achieved, 3), "peak": round(PEAK_TOPS, 2), "unit": "T lane-cycles/s",
-                     "frac": round(achieved / PEAK_TOPS, 4), "traffic": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY),
-                     "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.txt)",
-                     "kernel": "k_add<addr33>", "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch),
-                     "valu_instr_per_key": OPS_PER_KEY, "lane_cycles_per_key": round(LANE_CYCLES_PER_KEY, 1), "kernel_mkeys_s": round(keys_per_launch / (ms_launch * 1e3), 2) if ms_launch else 0,
-                     "valu_busy_pct_profiled": VALU_BUSY_PCT,
-                     "hbm_gbs": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9, 1) if ms_launch else 0,
-                     "hbm_frac_of_peak": round(keys_per_launch * TRAFFIC_BYTES_PER_KEY / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_launch else 0},
+        "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})",
+        "value": round(main_leg["value"], 2), "unit": "Mkeys/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_leg["ms_per_step"], 3),
+        "higher_is_better": True, "scaling": order[0], "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"add addr33, {what}, .blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
+                   "keys_per_gpu_per_step": per_gpu, "parallelism": f"range-sharded x{world}, no collective",
+                   "found_per_step": main_leg["found"], "planted_checked": main_leg["planted_checked"],
+                   "setup_ms_per_step_on_device": round(main_leg["setup_ms"] / args.steps, 3), "process_setup_s": round(t_setup, 2)},
+        "roofline": add_roofline(ms_launch, keys_per_launch),
     }
+    for m in order[1:]:
+        res[m + "_scaling"] = {"value": round(out[m]["value"], 2), "unit": "Mkeys/s", "ms_per_step": round(out[m]["ms_per_step"], 3),
+                               "steps": min(args.steps, 5), "keys_per_gpu_per_step": legs[m][1]}
     if not headline:
         hashes_per_key = len(args.addr) * (6 if args.endo else 1)
         res["config"]["workload"] = res["config"]["workload"].replace("add addr33", f"add -a {args.addr}{' -endo' if args.endo else ''}")
         res["config"]["hashes_per_key"] = hashes_per_key
-        res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: algorithmic op count not priced", "ms_per_launch": round(ms_launch, 3),
-                           "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(value * hashes_per_key / 1e3, 2)}
+        res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: no PMC profile of this kernel is loaded", "ms_per_launch": round(ms_launch, 3),
+                           "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(main_leg["value"] * hashes_per_key / 1e3, 2)}
     if world == 1 and not args.no_cpu and headline:
         cb, (log2n, cpu_lines) = cpu_baseline(words)
         res["cpu_baseline"] = cb
-        gpu_lines = sorted(r.line() for r in ks.found if r.pk < RANGE_A + (1 << log2n))
-        res["config"]["found_list_matches_cpu_on_sample"] = (gpu_lines == cpu_lines) if log2n <= args.keys_log2 else None
-        if log2n <= args.keys_log2 and gpu_lines != cpu_lines:
-            sys.stderr.write(f"[bench] FOUND LIST MISMATCH on the CPU sample: gpu {len(gpu_lines)} cpu {len(cpu_lines)}\n")
+        if log2n <= args.keys_log2:
+            gpu_lines = [l for l in main_leg["found_lines"] if int(l.split("\t")[2], 16) < RANGE_A + (1 << log2n)]
+            res["config"]["found_list_matches_cpu_on_sample"] = gpu_lines == cpu_lines
+            if gpu_lines != cpu_lines:
+                print(json.dumps(res))
+                raise SystemExit(f"[bench] FOUND LIST MISMATCH on the CPU sample: gpu {len(gpu_lines)} lines, cpu {len(cpu_lines)} lines")
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -27,7 +27,8 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
-    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod",
+    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing",
 ]
 
 _lib = None
@@ -61,6 +62,10 @@ def load():
     lib.ecl_hip_get_geometry.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_reset_timing.argtypes = [P]
+    lib.ecl_hip_get_setup_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.ecl_hip_get_mul_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ecl_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.ecl_hip_unpin_host.argtypes = [C.c_void_p]
     lib.ecl_hip_selftest.argtypes = [P]
     lib.ecl_hip_strerror.argtypes = [C.c_int]
     lib.ecl_hip_strerror.restype = C.c_char_p
@@ -173,6 +178,18 @@ class Device:
 
     def reset_timing(self):
         self._chk(self.lib.ecl_hip_reset_timing(self.h))
+
+    def setup_timing(self):
+        """-> (ms spent in the set-up kernels of non-contiguous add_range calls, number of such calls)"""
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(self.lib.ecl_hip_get_setup_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def mul_timing(self):
+        """-> (ms of mul_batch on the device incl. the overlapped scalar copies, calls, scalars)"""
+        ms, calls, n = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.ecl_hip_get_mul_timing(self.h, C.byref(ms), C.byref(calls), C.byref(n)))
+        return ms.value, calls.value, n.value
 
     # ---- diagnostics
     def diag_fe(self, op, a, b=None):

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -113,20 +115,14 @@ __global__ void __launch_bounds__(256) k_init_centres_batched(const u32* __restr
 
 // `mul` command body (main.c:530-534, 458-479): public key of each scalar by the fixed-base window method of
 // ec_gtable_mul (lib/ecc.c:876-929: W = 14, 19 windows, table slot (2^14-1)*i + b-1 = b * 2^(14 i) * G), then
-// hash + probe.  One lane = one scalar: <= 19 mixed additions of table points (64-byte gathers, the 19.9 MB table
-// lives in L2 / Infinity Cache) and one inversion.  The scalar 0 yields no point (the reference emits garbage).
+// ec_jacobi_grprdc (lib/ecc.c:695-707: ONE inversion for the whole batch), then hash + probe.
+// <= 19 mixed additions of table points per scalar (64-byte gathers, the 19.9 MB table lives in L2 / Infinity Cache).
+// The scalar 0 (mod n) yields no point (the reference emits garbage).
 #define GT_W 14u
-#define MUL_CHUNK (1u << 18)  /* scalars per staged chunk of ecl_hip_mul_batch (8 MB) */
+#define MUL_CHUNK (1u << 22)  /* scalars per staged chunk of ecl_hip_mul_batch (128 MB): 2^18 threads x MUL_R */
 #define GT_WINDOWS 19u
 #define GT_PER ((1u << GT_W) - 1u)
-template <bool A33, bool A65>
-__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const u32* __restrict__ gtab, add_args a) {
-  u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  u32 kk[9];
-#pragma unroll
-  for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
-  kk[8] = 0;
+__device__ __forceinline__ jac gtable_mul(const u32 kk[9], const u32* __restrict__ gtab) {
   jac acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
 #pragma unroll 1
@@ -142,9 +138,73 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
     const u32* e = gtab + ((size_t)w * GT_PER + digit - 1) * 16;
     acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
   }
+  return acc;
+}
+// One thread owns MUL_R scalars (i = t, t + nt, ...: a wave reads 2 KiB of contiguous scalars per round): their window
+// sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
+// per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
+// the reference's 2048-key job): 209 + 17 + 7 multiplications per scalar instead of 209 + 270 + 3.
+#define MUL_R 16u  /* at most; short batches take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
+template <bool A33, bool A65>
+__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const u32* __restrict__ gtab, add_args a,
+                                                   u32* __restrict__ tmp, u32 nt, u32 R) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nt) return;
+  fe prod = fe_one();
+  u32 infmask = 0;
+#pragma unroll 1
+  for (u32 r = 0; r < R; ++r) {
+    const u32 i = r * nt + t;
+    if (i >= n) break;
+    u32 kk[9];
+    const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
+    kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
+    const jac acc = gtable_mul(kk, gtab);
+    const fe z = acc.inf ? fe_one() : acc.Z;
+    infmask |= (acc.inf ? 1u : 0u) << r;
+    u32* p = tmp + (size_t)r * 36 * nt + t;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      p[(size_t)l * nt] = acc.X.n[l], p[(size_t)(9 + l) * nt] = acc.Y.n[l];
+      p[(size_t)(18 + l) * nt] = z.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+    }
+    prod = fe_mul(prod, z);
+  }
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = R; r-- > 0;) {
+    const u32 i = r * nt + t;
+    if (i >= n) continue;
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, Z, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      Z.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe zi = fe_mul(inv, pre);
+    inv = fe_mul(inv, Z);
+    if ((infmask >> r) & 1u) continue;
+    const fe zi2 = fe_sqr(zi);
+    const fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
+    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
+  }
+}
+// k*G of ONE scalar (kernel argument) through the window table: the base centre of a non-contiguous add call.
+// 19 mixed additions + one inversion (~0.1 ms) instead of the 256-step double-and-add of k_mul_g (~1.2 ms of latency).
+struct scalar_arg { u32 w[8]; };
+__global__ void __launch_bounds__(64) k_mul_window_one(scalar_arg s, const u32* __restrict__ gtab, u32* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 kk[9];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = s.w[w];
+  kk[8] = 0;
   fe x, y;
-  if (!jac_to_affine(x, y, acc)) return;
-  check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
+  jac_to_affine(x, y, gtable_mul(kk, gtab));  // never infinity: the range check excludes the scalar 0
+  u32 xw[8], yw[8];
+  fe_to_words(xw, x), fe_to_words(yw, y);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) out[w] = xw[w], out[8 + w] = yw[w];
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
@@ -228,7 +288,8 @@ struct ecl_hip {
   uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
   // `mul`: scalars travel in chunks through two pinned staging buffers, copy engine and kernel overlapped
-  u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr};
+  u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr}; u32 kbuf_cap = 0;
+  u32* d_multmp = nullptr;                     // parked Jacobian sums of one chunk (144 bytes per scalar)
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
@@ -240,9 +301,11 @@ struct ecl_hip {
   bool B_auto = true;  // half group not fixed by the caller: short calls take a smaller one (see ecl_hip_add_range)
   u256 walk_next;  // scalar (mod n) the resident centres are positioned for
   u32 jump_host[16];
+  u32 aux_B = 0, aux_T = 0;  // geometry the jump and the ladder in d_aux / jump_host were computed for
   // timing
-  double kernel_ms = 0;
-  uint64_t launches = 0, keys = 0;
+  double kernel_ms = 0, setup_ms = 0, mul_ms = 0;
+  uint64_t launches = 0, keys = 0, setups = 0, mul_calls = 0, mul_scalars = 0;
+  hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;
 };
 
 #define HIPCHK(h, call)                                                                    \
@@ -292,12 +355,27 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreate(&h->ev0));
   HIPCHK(h, hipEventCreate(&h->ev1));
+  HIPCHK(h, hipEventCreate(&h->ev_s0));
+  HIPCHK(h, hipEventCreate(&h->ev_s1));
   HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_counter, 2 * sizeof(u32)));
+  // the self-test checks the CODE (known answers, walk kernel against the double-and-add kernel): once per process
+  // for every (device, kernel selection) is enough - eight handles for eight shards of one scan do not repeat it
+  static std::mutex mu;
+  static std::set<u32> passed;
   const char* skip = getenv("ECL_HIP_SKIP_SELFTEST");
-  if (!(skip && skip[0] == '1')) return ecl_hip_selftest(h);
-  return ECL_OK;
+  const u32 key = (u32)device * 8u + flags;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if ((skip && skip[0] == '1') || passed.count(key)) return ECL_OK;
+  }
+  const int rc = ecl_hip_selftest(h);
+  if (rc == ECL_OK) {
+    std::lock_guard<std::mutex> lk(mu);
+    passed.insert(key);
+  }
+  return rc;
 }
 
 void ecl_hip_close(ecl_hip* h) {
@@ -313,6 +391,9 @@ void ecl_hip_close(ecl_hip* h) {
     if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  (void)hipFree(h->d_multmp);
+  if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
+  if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -326,9 +407,21 @@ int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
   if (h->d_bloom) HIPCHK(h, hipFree(h->d_bloom));
   h->d_bloom = nullptr, h->bloom_words = 0;
   HIPCHK(h, hipMalloc(&h->d_bloom, nwords * sizeof(u64)));
-  HIPCHK(h, hipMemcpy(h->d_bloom, bits, nwords * sizeof(u64), hipMemcpyHostToDevice));
+  // on the handle's own stream: device threads upload in parallel, each over its own PCIe link; a buffer pinned with
+  // ecl_hip_pin_host goes by DMA at link rate, a pageable one is staged by the runtime
+  HIPCHK(h, hipMemcpyAsync(h->d_bloom, bits, nwords * sizeof(u64), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->bloom_words = nwords;
   return ECL_OK;
+}
+
+int ecl_hip_pin_host(const void* p, size_t bytes) {
+  if (!p || !bytes) return ECL_E_ARG;
+  return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess ? ECL_OK : ECL_E_HIP;
+}
+int ecl_hip_unpin_host(const void* p) {
+  if (!p) return ECL_E_ARG;
+  return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? ECL_OK : ECL_E_HIP;
 }
 
 int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
@@ -372,7 +465,14 @@ int ecl_hip_get_timing(ecl_hip* h, double* kernel_ms, uint64_t* launches, uint64
 }
 int ecl_hip_reset_timing(ecl_hip* h) {
   if (!h) return ECL_E_ARG;
-  h->kernel_ms = 0, h->launches = 0, h->keys = 0;
+  h->kernel_ms = 0, h->launches = 0, h->keys = 0, h->setup_ms = 0, h->setups = 0;
+  h->mul_ms = 0, h->mul_calls = 0, h->mul_scalars = 0;
+  return ECL_OK;
+}
+int ecl_hip_get_setup_timing(ecl_hip* h, double* setup_ms, uint64_t* setups) {
+  if (!h) return ECL_E_ARG;
+  if (setup_ms) *setup_ms = h->setup_ms;
+  if (setups) *setups = h->setups;
   return ECL_OK;
 }
 
@@ -569,12 +669,15 @@ static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
   return ECL_OK;
 }
 
+static int ensure_gtable(ecl_hip* h);
+
 extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
   if (!h || nkeys == 0) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
+  if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
   if (!nkeys_ok(h, nkeys)) return ECL_E_ARG;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
@@ -620,18 +723,31 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   }
   bool cont = h->walk_valid && h->walk_T == T && h->walk_B == B && u256_eq(h->walk_next, k0);
   if (!cont) {
-    // C0 = (k0 + B*s)*G, jump = (T*2B*s)*G, ladder_j = (2^j * 2B*s)*G
-    u256 d = sc_mul_u64(s, group);
-    std::vector<u32> ks(34 * 8);
-    words_of(&ks[0], sc_add(k0, sc_mul_u64(s, B)));
-    words_of(&ks[8], sc_mul_u64(d, T));
-    u256 l = d;
-    for (int j = 0; j < 32; ++j) {
-      words_of(&ks[(size_t)(2 + j) * 8], l);
-      l = sc_add(l, l);
+    if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_s0, h->stream));
+    if (h->aux_B != B || h->aux_T != T) {
+      // jump = (T*2B*s)*G and the ladder 2^j * (2B*s)*G depend on the geometry only: kept across calls
+      h->aux_B = h->aux_T = 0;
+      const u256 d = sc_mul_u64(s, group);
+      std::vector<u32> ks(33 * 8);
+      words_of(&ks[0], sc_mul_u64(d, T));
+      u256 l = d;
+      for (int j = 0; j < 32; ++j) {
+        words_of(&ks[(size_t)(1 + j) * 8], l);
+        l = sc_add(l, l);
+      }
+      HIPCHK(h, hipMemcpyAsync(h->d_auxk, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(k_mul_g, dim3(1), dim3(64), 0, h->stream, h->d_auxk, h->d_aux + 16, (u8*)nullptr, 33u);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      h->aux_B = B, h->aux_T = T;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_auxk, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_mul_g, dim3(1), dim3(64), 0, h->stream, h->d_auxk, h->d_aux, (u8*)nullptr, 34u);
+    // C0 = (k0 + B*s)*G through the window table (19 additions, ~0.1 ms), the scalar travelling as a kernel argument;
+    // then the lane centres C0 + g*D.  Nothing here waits for the host: the search kernel queues right behind.
+    scalar_arg c0;
+    words_of(c0.w, sc_add(k0, sc_mul_u64(s, B)));
+    hipLaunchKernelGGL(k_mul_window_one, dim3(1), dim3(64), 0, h->stream, c0, h->d_gtab, h->d_aux);
     HIPCHK(h, hipGetLastError());
     if (B >= 8)  // the chain scratch (T * B * 36 bytes) holds the 144 bytes per lane the batched set-up parks
       hipLaunchKernelGGL(k_init_centres_batched, dim3((T / INIT_R + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32,
@@ -639,8 +755,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     else
       hipLaunchKernelGGL(k_init_centres, dim3(T / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32, h->d_cxy, T);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_s1, h->stream));
     h->walk_T = T, h->walk_B = B;
   }
   add_args a;
@@ -661,6 +776,10 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->kernel_ms += ms, h->launches += 1, h->keys += nkeys;
+  if (!cont) {
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_s0, h->ev_s1));
+    h->setup_ms += ms, h->setups += 1;
+  }
 
   // the centres now sit at the start of group nb*T + g: valid continuation only if the launch was exact
   const u64 walked = (u64)nb * T * group;
@@ -707,10 +826,30 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   if (!h->copy_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
-      HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)MUL_CHUNK * 32));
-      HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)MUL_CHUNK * 32, hipHostMallocDefault));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+    }
+  }
+  {
+    // staging for one chunk (x2: the copy engine runs one chunk ahead of the kernel): sized to the call, grown on demand
+    u32 want = 1u << 16;
+    while (want < MUL_CHUNK && want < n) want <<= 1;
+    if (want > h->kbuf_cap) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+      for (int i = 0; i < 2; ++i) {
+        if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
+        if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
+        h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
+      }
+      if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
+      h->d_multmp = nullptr, h->kbuf_cap = 0;
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
+        HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)want * 32, hipHostMallocDefault));
+      }
+      HIPCHK(h, hipMalloc(&h->d_multmp, (size_t)want * 36 * sizeof(u32)));
+      h->kbuf_cap = want;
     }
   }
   add_args a;
@@ -721,24 +860,44 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum over 19 x 14 bits is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  for (u32 at = 0, c = 0; at < n; at += MUL_CHUNK, ++c) {
-    const u32 m = n - at < MUL_CHUNK ? n - at : MUL_CHUNK, b = c & 1;
+  const u32 chunk = h->kbuf_cap;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  for (u32 at = 0, c = 0; at < n; at += chunk, ++c) {
+    const u32 m = n - at < chunk ? n - at : chunk, b = c & 1;
     if (c >= 2) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel two chunks back is done with this pair
     memcpy(h->pin_k[b], scalars[at], (size_t)m * 32);
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], h->pin_k[b], (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-    dim3 grid((m + 255) / 256), blk(256);
-    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
-    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
-    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a);
+    // scalars per thread: as many as keep >= 2^18 threads in flight (the chip holds 2^18 at 4 blocks per CU), at most MUL_R
+    u32 R = m >> 18;
+    R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
+    const u32 nt = (m + R - 1) / R;
+    dim3 grid((nt + 255) / 256), blk(256);
+    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a, h->d_multmp, nt, R);
+    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a, h->d_multmp, nt, R);
+    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_gtab, a, h->d_multmp, nt, R);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
   }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;
   rc = collect_found(h, cap, rcap, out, &cnt, false);
   *nout = cnt;
+  if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));  // copies + kernels of this call, as the stream saw them
+    h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
+  }
   return rc;
+}
+
+extern "C" int ecl_hip_get_mul_timing(ecl_hip* h, double* ms, uint64_t* calls, uint64_t* scalars) {
+  if (!h) return ECL_E_ARG;
+  if (ms) *ms = h->mul_ms;
+  if (calls) *calls = h->mul_calls;
+  if (scalars) *scalars = h->mul_scalars;
+  return ECL_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics (host)

@@ -62,6 +62,73 @@ K32_3(k_perm_b32, "v_perm_b32")
 K32_3(k_lshl_add_u32, "v_lshl_add_u32")
 K32_3(k_mad_i32_i24, "v_mad_i32_i24")
 
+// ---- round 2: is there a 2-cycle wave64 issue (MI355X_MICROARCH.md: "v_fma_f32 (wave64) 2 cyc") and for which opcodes?
+// Same 8 independent chains per lane, but every chain has its OWN source registers (spread over the register banks),
+// and the float forms in their VOP2 (e32) encodings next to the VOP3 one measured in round 1.
+#define K32_2D(NAME, OPSTR)                                                                     \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a[8];                                                                        \
+    for (int i = 0; i < 8; ++i) a[i] = (seed ^ threadIdx.x) * (2 * i + 5), r[i] = a[i] * (i + 3); \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                           \
+          asm volatile(OPSTR " %0, %0, %1" : "+v"(r[i]) : "v"(a[i]));                           \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+#define K32_3D(NAME, OPSTR, TAIL)                                                               \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a[8], b[8];                                                                  \
+    for (int i = 0; i < 8; ++i) a[i] = (seed ^ threadIdx.x) * (2 * i + 5), b[i] = a[i] * 7 + 1, r[i] = a[i] * (i + 3); \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                           \
+          asm volatile(OPSTR " %0, %0, %1, %2" TAIL : "+v"(r[i]) : "v"(a[i]), "v"(b[i]));       \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+// one source: d = op(a) into 8 destinations (VOP1)
+#define K32_1(NAME, OPSTR)                                                                      \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a[8];                                                                        \
+    for (int i = 0; i < 8; ++i) a[i] = (seed ^ threadIdx.x) * (2 * i + 5), r[i] = 0;            \
+    for (int it = 0; it < ITERS; ++it) {                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                           \
+          asm volatile(OPSTR " %0, %1" : "+v"(r[i]) : "v"(a[i]));                               \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];                                      \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+K32_2D(k_fmac_f32_e32, "v_fmac_f32_e32")
+K32_2D(k_mul_f32_e32, "v_mul_f32_e32")
+K32_2D(k_add_f32_e32, "v_add_f32_e32")
+K32_2D(k_add_u32_d, "v_add_u32_e32")
+K32_2D(k_or_b32_d, "v_or_b32_e32")
+K32_2D(k_lshrrev_b32_d, "v_lshrrev_b32_e32")
+K32_2D(k_min_u32_d, "v_min_u32_e32")
+K32_2D(k_cndmask_d, "v_cndmask_b32_e32")
+K32_2D(k_mul_lo_u16_d, "v_mul_lo_u16_e32")
+K32_2D(k_pk_mul_lo_u16_d, "v_pk_mul_lo_u16")
+K32_1(k_mov_b32, "v_mov_b32_e32")
+K32_1(k_not_b32, "v_not_b32_e32")
+K32_1(k_bfrev_b32, "v_bfrev_b32_e32")
+K32_3D(k_fma_f32_d, "v_fma_f32", "")
+K32_3D(k_bitop3_d, "v_bitop3_b32", " bitop3:0x96")
+K32_3D(k_bfe_u32_d, "v_bfe_u32", "")
+K32_3D(k_xad_u32_d, "v_xad_u32", "")
+K32_3D(k_or3_b32_d, "v_or3_b32", "")
+K32_3D(k_add_lshl_u32_d, "v_add_lshl_u32", "")
+K32_3D(k_alignbit_d, "v_alignbit_b32", "")
+K32_3D(k_add3_d, "v_add3_u32", "")
+K32_3D(k_mad_u32_u16_d, "v_mad_u32_u16", "")
+K32_3D(k_dot4_u32_u8_d, "v_dot4_u32_u8", "")
+
 // carry chain: v_add_co_u32 + v_addc_co_u32 pairs (VOP2, implicit vcc)
 __global__ void k_addc_pair(uint32_t* out, uint32_t seed) {
   uint32_t r[8], a = seed ^ threadIdx.x;
@@ -308,6 +375,17 @@ int main(int argc, char** argv) {
       {"v_mad_u64_u32 dependent chain", k_mad_u64_dep, 32}, {"v_add_u32 dependent chain", k_add_dep, 32},
       {"mix 16 add + 16 alignbit, alternating", k_mix_alternating, 32}, {"mix 16 add + 16 alignbit, grouped by 8", k_mix_grouped, 32},
       {"mix 8 add + 24 alignbit (1:3)", k_mix_1to3, 32},
+      // round 2: distinct source registers per chain; VOP2 float forms; more opcodes of the hash / limb arithmetic
+      {"v_fmac_f32_e32  (distinct regs)", k_fmac_f32_e32, 32}, {"v_mul_f32_e32   (distinct regs)", k_mul_f32_e32, 32},
+      {"v_add_f32_e32   (distinct regs)", k_add_f32_e32, 32}, {"v_fma_f32 VOP3  (distinct regs)", k_fma_f32_d, 32},
+      {"v_add_u32_e32   (distinct regs)", k_add_u32_d, 32}, {"v_or_b32_e32    (distinct regs)", k_or_b32_d, 32},
+      {"v_mov_b32_e32", k_mov_b32, 32}, {"v_not_b32_e32", k_not_b32, 32}, {"v_bfrev_b32_e32", k_bfrev_b32, 32},
+      {"v_cndmask_b32_e32 (vcc)", k_cndmask_d, 32}, {"v_min_u32_e32", k_min_u32_d, 32}, {"v_lshrrev_b32_e32 (distinct regs)", k_lshrrev_b32_d, 32},
+      {"v_mul_lo_u16_e32", k_mul_lo_u16_d, 32}, {"v_pk_mul_lo_u16", k_pk_mul_lo_u16_d, 32},
+      {"v_bitop3_b32    (distinct regs)", k_bitop3_d, 32}, {"v_alignbit_b32  (distinct regs)", k_alignbit_d, 32},
+      {"v_add3_u32      (distinct regs)", k_add3_d, 32}, {"v_bfe_u32", k_bfe_u32_d, 32}, {"v_xad_u32", k_xad_u32_d, 32},
+      {"v_or3_b32", k_or3_b32_d, 32}, {"v_add_lshl_u32", k_add_lshl_u32_d, 32}, {"v_mad_u32_u16", k_mad_u32_u16_d, 32},
+      {"v_dot4_u32_u8", k_dot4_u32_u8_d, 32},
       {"mix 16 add + 16 alignbit, in pairs", k_mix_pairs, 32}, {"mix 4 add (2 pairs) + 28 alignbit", k_mix_pair_in_14, 32},
   };
   int waves_per_simd = argc > 1 ? atoi(argv[1]) : 8;

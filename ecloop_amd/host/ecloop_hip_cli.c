@@ -34,7 +34,7 @@
 #define GROUP_INV_SIZE 2048ull     /* main.c:17 */
 #define MAX_JOB_SIZE (2ull << 20)  /* main.c:16 */
 #define MAX_LINE_SIZE 1025         /* main.c:18 */
-#define LAUNCH_KEYS (1ull << 30)   /* keys per device call */
+#define LAUNCH_KEYS (1ull << 32)   /* keys per device call on one GPU: one sweep of the default walk geometry */
 #define MAX_GPUS 64
 
 typedef unsigned __int128 u128;
@@ -237,7 +237,7 @@ typedef struct ctx_t {
   int ngpus;
   ecl_hip *dev[MAX_GPUS];
   u64 k_checked, k_found;
-  bool a33, a65, endo, quiet, use_color, raw_text, has_seed, finished;
+  bool a33, a65, endo, quiet, use_color, raw_text, bin_input, parse_only, has_seed, finished;
   FILE *outfile;
   u64 ts_started, ts_updated, ts_printed;
   volatile bool paused; /* 'p' / 'r' on the terminal (main.c:41-46,874-888) */
@@ -359,33 +359,69 @@ static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *
 }
 
 /* ------------------------------------------------------------------------------------------- add */
-typedef struct { ctx_t *ctx; int g; sc start; u64 nkeys; u64 status_total, keys_total; } add_job;
+/* One scan = the contiguous run of keys  rs + i*stride, i < hashed  (what cmd_add's jobs hash, main.c:405-454).  The
+   device threads pull chunks of it from a shared counter, like the reference's workers pull 2^21-key jobs
+   (main.c:418-431): a GPU that sustains a few percent more clock simply takes more chunks, and a scan of any length
+   (the default range 0x800:p included) streams through without its key count having to fit 64 bits. */
+typedef struct {
+  ctx_t *ctx;
+  sc rs;             /* first scalar */
+  sc hashed;         /* keys to hash (256-bit: `add` without -r walks ~2^256 / stride keys) */
+  sc next;           /* keys handed out so far */
+  u64 chunk;         /* keys per hand-out = per device call */
+  u64 status_total;  /* what the status counter must have gained at the end (0: not representable, add as we go) */
+  u64 status_given;
+  u64 mult;          /* status units per key when status_total is 0 */
+  pthread_mutex_t mu;
+} scan_t;
+typedef struct { scan_t *scan; int g; } scan_worker_t;
 
-/* hash `nkeys` keys from `start` on GPU g in launches of LAUNCH_KEYS, report hits */
-static void *add_worker(void *arg) {
-  add_job *j = arg;
-  ctx_t *ctx = j->ctx;
-  u32 cap = 4096, half_group = 0, lanes = 0;
+static sc sc_add_u64_raw(sc a, u64 v) {
+  sc b = sc_u64(v), r;
+  sc_addraw(&r, &a, &b);
+  return r;
+}
+/* scalar of key number `off` (256-bit count): rs + off * stride (mod n); stride is a power of two */
+static sc scan_scalar(const ctx_t *ctx, const sc *rs, const sc *off) {
+  sc o = sc_reduce(*off); /* off < 2^256 < 2n */
+  return sc_add(sc_reduce(*rs), sc_mul(ctx->stride_k, o));
+}
+
+static void *scan_worker(void *arg) {
+  scan_worker_t *w = arg;
+  scan_t *sn = w->scan;
+  ctx_t *ctx = sn->ctx;
+  u32 cap = 4096;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
-  /* launches of whole sweeps (lanes * 2 * half_group keys) keep every lane busy and continue without re-init */
-  u64 per = LAUNCH_KEYS;
-  if (ecl_hip_get_geometry(ctx->dev[j->g], &half_group, &lanes) == ECL_OK && lanes) {
-    u64 sweep = (u64)lanes * 2 * half_group;
-    per = LAUNCH_KEYS / sweep * sweep;
-    if (per < sweep) per = sweep;
-  }
-  for (u64 done = 0; done < j->nkeys;) {
-    u64 n = j->nkeys - done;
-    if (n > LAUNCH_KEYS && n > per) n = per; /* what fits one launch goes as one call: the library sizes the lanes to it */
-    sc s = sc_add(sc_reduce(j->start), sc_mul(ctx->stride_k, sc_u64(done)));
+  for (;;) {
+    pthread_mutex_lock(&sn->mu);
+    sc lo = sn->next, left;
+    if (sc_cmp(&lo, &sn->hashed) >= 0) { pthread_mutex_unlock(&sn->mu); break; }
+    sc_subraw(&left, &sn->hashed, &lo);
+    u64 n = (left.w[1] | left.w[2] | left.w[3]) || left.w[0] > sn->chunk ? sn->chunk : left.w[0];
+    sn->next = sc_add_u64_raw(lo, n);
+    bool last = sc_cmp(&sn->next, &sn->hashed) >= 0;
+    /* status counter: the reference adds job_size (x6 with endo) per job (main.c:431); spread over the chunks */
+    u64 st;
+    if (!sn->status_total) st = n * sn->mult;
+    else if (last) st = sn->status_total - sn->status_given;
+    else {
+      u128 done = (u128)sn->next.w[0]; /* status_total != 0 implies hashed < 2^63 */
+      u64 upto = (u64)((u128)sn->status_total * done / sn->hashed.w[0]);
+      st = upto - sn->status_given;
+    }
+    sn->status_given += st;
+    pthread_mutex_unlock(&sn->mu);
+
+    sc s = scan_scalar(ctx, &sn->rs, &lo);
     u32 cnt = 0;
     int rc;
     for (;;) {
-      rc = ecl_hip_add_range(ctx->dev[j->g], s.w, n, buf, cap, &cnt);
+      rc = ecl_hip_add_range(ctx->dev[w->g], s.w, n, buf, cap, &cnt);
       if (rc != ECL_E_OVERFLOW) break;
       cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap); /* dense filter: rerun with a buffer that fits */
     }
-    if (rc != ECL_OK) die_ecl(ctx, j->g, rc, "add_range");
+    if (rc != ECL_OK) die_ecl(ctx, w->g, rc, "add_range");
     u32 kept = 0;
     sc *pks = cnt ? malloc(sizeof(sc) * cnt) : NULL;
     for (u32 i = 0; i < cnt; ++i) {
@@ -393,77 +429,85 @@ static void *add_worker(void *arg) {
       pks[kept] = calc_priv(s, ctx->stride_k, buf[i].key_offset, buf[i].endo);
       buf[kept++] = buf[i];
     }
-    pk_verify_hashes(ctx, j->g, pks, buf, kept);
+    pk_verify_hashes(ctx, w->g, pks, buf, kept);
     for (u32 i = 0; i < kept; ++i) ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pks[i]);
     free(pks);
-    done += n;
-    /* status counter: the reference adds job_size (x6 with endo) per job (main.c:431); spread it over the launches */
-    u64 before = (u64)((u128)j->status_total * (done - n) / j->keys_total);
-    u64 after = (u64)((u128)j->status_total * done / j->keys_total);
-    ctx_update(ctx, after - before);
+    ctx_update(ctx, st);
   }
   free(buf);
   return NULL;
 }
 
-/* cmd_add (main.c:437-454) over [range_s, range_e): same keys hashed, same counters, sharded over the GPUs */
+/* keys per hand-out.  One GPU: whole sweeps of the walk (2^32 keys at the default geometry), which continue on the
+   device without re-initialisation.  Several GPUs: at least two chunks per GPU so that uneven clocks even out, at
+   least 2^27 keys (10 ms of kernel against ~0.4 ms of per-call set-up), at most 2^30. */
+static u64 scan_chunk(const ctx_t *ctx, const sc *hashed) {
+  if (ctx->ngpus <= 1) return LAUNCH_KEYS;
+  if (hashed->w[1] | hashed->w[2] | hashed->w[3]) return 1ull << 30;
+  u64 c = (hashed->w[0] + 2 * (u64)ctx->ngpus - 1) / (2 * (u64)ctx->ngpus);
+  c = (c + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
+  if (c < (1ull << 27)) c = 1ull << 27;
+  if (c > (1ull << 30)) c = 1ull << 30;
+  return c;
+}
+
+/* cmd_add (main.c:437-454) over [range_s, range_e): same keys hashed, same counters, spread over the GPUs */
 static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
   sc span;
   sc_subraw(&span, &re, &rs);
   /* cmd_rnd always uses MAX_JOB_SIZE jobs, even for a narrower window (main.c:624) */
   bool small = !full_jobs && !(span.w[1] | span.w[2] | span.w[3]) && span.w[0] < MAX_JOB_SIZE;
   u64 job = small ? span.w[0] : MAX_JOB_SIZE; /* main.c:442 */
-  /* njobs = ceil(span / (job * stride)) (main.c:420-427): count by stepping like the reference's counter */
-  sc inc = sc_mul(ctx->stride_k, sc_u64(job));
-  u64 njobs = 0;
-  if (small && ctx->ord_offs == 0) njobs = 1;
-  else {
-    /* span / (job*stride): both are < 2^256; do it by long division on the top 128 bits when stride is a power of two */
-    sc cur = rs;
-    /* fast path: job*stride = 2^(21+offs) (job = 2^21) or small job: iterate at most a few steps */
-    if (!small) {
-      unsigned sh = 21 + ctx->ord_offs;
-      if (sh >= 256) njobs = 1;
-      else {
-        /* njobs = ceil(span / 2^sh) */
-        sc q = {{0, 0, 0, 0}};
-        for (unsigned b = sh; b < 256; ++b)
-          if ((span.w[b >> 6] >> (b & 63)) & 1) q.w[(b - sh) >> 6] |= 1ULL << ((b - sh) & 63);
-        bool rem = false;
-        for (unsigned b = 0; b < sh; ++b)
-          if ((span.w[b >> 6] >> (b & 63)) & 1) rem = true;
-        if (q.w[1] | q.w[2] | q.w[3]) { fprintf(stderr, "range too large for one run: narrow -r or raise -d\n"); exit(1); }
-        njobs = q.w[0] + (rem ? 1 : 0);
-      }
-    } else {
-      while (sc_cmp(&cur, &re) < 0 && njobs < (1u << 20)) {
-        sc nx;
-        if (sc_addraw(&nx, &cur, &inc)) { njobs++; break; }
-        cur = nx, njobs++;
-      }
+  /* njobs = ceil(span / (job * stride)) (main.c:420-427): the counter steps by job*stride until it reaches range_e */
+  sc njobs = {{0, 0, 0, 0}};
+  if (small && ctx->ord_offs == 0) njobs = sc_u64(1);
+  else if (!small) {
+    unsigned sh = 21 + ctx->ord_offs; /* job * stride = 2^sh */
+    if (sh >= 256) njobs = sc_u64(1);
+    else {
+      for (unsigned b = sh; b < 256; ++b)
+        if ((span.w[b >> 6] >> (b & 63)) & 1) njobs.w[(b - sh) >> 6] |= 1ULL << ((b - sh) & 63);
+      bool rem = false;
+      for (unsigned b = 0; b < sh; ++b)
+        if ((span.w[b >> 6] >> (b & 63)) & 1) rem = true;
+      if (rem) njobs = sc_add_u64_raw(njobs, 1);
     }
+  } else { /* a sub-2^21 job with a stride: step like the reference's counter (at most 2^21 / 2^offs + 1 steps) */
+    sc inc = sc_mul(ctx->stride_k, sc_u64(job)), cur = rs;
+    u64 n = 0;
+    while (sc_cmp(&cur, &re) < 0 && n < (1u << 22)) {
+      sc nx;
+      n++;
+      if (sc_addraw(&nx, &cur, &inc)) break;
+      cur = nx;
+    }
+    njobs = sc_u64(n);
   }
   u64 per_job = (job + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
-  u64 hashed = (njobs - 1) * job + per_job; /* contiguous run of keys actually hashed */
-  u64 status_total = njobs * job * (ctx->endo ? 6 : 1);
-  int ng = ctx->ngpus;
-  u64 per = (hashed + ng - 1) / ng;
-  per = (per + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
-  pthread_t th[MAX_GPUS];
-  add_job jobs[MAX_GPUS];
-  int started = 0;
-  u64 status_given = 0;
-  for (int g = 0; g < ng; ++g) {
-    u64 lo = (u64)g * per < hashed ? (u64)g * per : hashed;
-    u64 hi = lo + per < hashed ? lo + per : hashed;
-    if (hi == lo) continue;
-    u64 st_hi = (u64)((u128)status_total * hi / hashed);
-    jobs[started] = (add_job){ctx, g, sc_add(sc_reduce(rs), sc_mul(ctx->stride_k, sc_u64(lo))), hi - lo, st_hi - status_given, hi - lo};
-    status_given = st_hi;
-    pthread_create(&th[started], NULL, add_worker, &jobs[started]);
-    started++;
+  scan_t sn;
+  memset(&sn, 0, sizeof sn);
+  sn.ctx = ctx, sn.rs = rs, sn.mult = ctx->endo ? 6 : 1;
+  pthread_mutex_init(&sn.mu, NULL);
+  if (!(njobs.w[1] | njobs.w[2] | njobs.w[3]) && njobs.w[0] < (1ull << 40)) {
+    /* the usual case: hashed = (njobs-1)*job + ceil(job/2048)*2048 keys, status counter = njobs*job (x6 with endo) */
+    sn.hashed = sc_u64((njobs.w[0] - 1) * job + per_job);
+    sn.status_total = njobs.w[0] * job * sn.mult;
+  } else {
+    /* astronomically long (e.g. the default range): hashed = njobs * 2^21 as a 256-bit count; it will not finish,
+       and the status counter advances by the keys of every chunk */
+    sc h = njobs;
+    for (int i = 0; i < 21; ++i) sc_addraw(&h, &h, &h); /* njobs < 2^235 here: no wrap */
+    sn.hashed = h;
   }
-  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  sn.chunk = scan_chunk(ctx, &sn.hashed);
+  pthread_t th[MAX_GPUS];
+  scan_worker_t ws[MAX_GPUS];
+  for (int g = 0; g < ctx->ngpus; ++g) {
+    ws[g] = (scan_worker_t){&sn, g};
+    pthread_create(&th[g], NULL, scan_worker, &ws[g]);
+  }
+  for (int g = 0; g < ctx->ngpus; ++g) pthread_join(th[g], NULL);
+  pthread_mutex_destroy(&sn.mu);
 }
 
 static void cmd_add(ctx_t *ctx) {
@@ -473,8 +517,9 @@ static void cmd_add(ctx_t *ctx) {
 }
 
 /* ------------------------------------------------------------------------------------------- mul */
-/* host SHA-256 of a passphrase for `-raw` (main.c:505-527): input preparation, not the search path */
-static void sha256_host(u32 st[8], const u8 *msg, size_t len) {
+/* host SHA-256 of a passphrase for `-raw` (main.c:505-527): input preparation, not the search path.  Block by block,
+   nothing allocated per line. */
+static void sha256_block(u32 st[8], const u8 *blk) {
   static const u32 K[64] = {
       0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
       0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
@@ -483,40 +528,42 @@ static void sha256_host(u32 st[8], const u8 *msg, size_t len) {
       0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
       0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
       0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-  static const u32 IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-  size_t total = (len + 9 + 63) / 64 * 64;
-  u8 *buf = calloc(total, 1);
-  memcpy(buf, msg, len);
-  buf[len] = 0x80;
-  for (int j = 0; j < 8; ++j) buf[total - 1 - j] = (u8)(((u64)len * 8) >> (8 * j));
-  memcpy(st, IV, 32);
 #define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
-  for (size_t off = 0; off < total; off += 64) {
-    u32 w[64], v[8];
-    for (int i = 0; i < 16; ++i)
-      w[i] = (u32)buf[off + 4 * i] << 24 | (u32)buf[off + 4 * i + 1] << 16 | (u32)buf[off + 4 * i + 2] << 8 | buf[off + 4 * i + 3];
-    for (int i = 16; i < 64; ++i)
-      w[i] = w[i - 16] + (ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
-             (ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10));
-    memcpy(v, st, 32);
-    for (int i = 0; i < 64; ++i) {
-      u32 t1 = v[7] + (ROR(v[4], 6) ^ ROR(v[4], 11) ^ ROR(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K[i] + w[i];
-      u32 t2 = (ROR(v[0], 2) ^ ROR(v[0], 13) ^ ROR(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
-      memmove(v + 1, v, 28);
-      v[4] += t1, v[0] = t1 + t2;
-    }
-    for (int i = 0; i < 8; ++i) st[i] += v[i];
+  u32 w[64], v[8];
+  for (int i = 0; i < 16; ++i) w[i] = (u32)blk[4 * i] << 24 | (u32)blk[4 * i + 1] << 16 | (u32)blk[4 * i + 2] << 8 | blk[4 * i + 3];
+  for (int i = 16; i < 64; ++i)
+    w[i] = w[i - 16] + (ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
+           (ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10));
+  memcpy(v, st, 32);
+  for (int i = 0; i < 64; ++i) {
+    u32 t1 = v[7] + (ROR(v[4], 6) ^ ROR(v[4], 11) ^ ROR(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K[i] + w[i];
+    u32 t2 = (ROR(v[0], 2) ^ ROR(v[0], 13) ^ ROR(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+    memmove(v + 1, v, 28);
+    v[4] += t1, v[0] = t1 + t2;
   }
+  for (int i = 0; i < 8; ++i) st[i] += v[i];
 #undef ROR
-  free(buf);
+}
+static void sha256_stream(u32 st[8], const u8 *msg, size_t len) {
+  static const u32 IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  memcpy(st, IV, 32);
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) sha256_block(st, msg + off);
+  u8 tail[128] = {0};
+  size_t rem = len - off, total = rem + 9 <= 64 ? 64 : 128;
+  memcpy(tail, msg + off, rem);
+  tail[rem] = 0x80;
+  for (int j = 0; j < 8; ++j) tail[total - 1 - j] = (u8)(((u64)len * 8) >> (8 * j));
+  sha256_block(st, tail);
+  if (total == 128) sha256_block(st, tail + 64);
 }
 
-static void mul_flush(ctx_t *ctx, u64 (*ks)[4], u32 n) {
+static void mul_flush(ctx_t *ctx, int g, u64 (*ks)[4], u32 n) {
   if (!n) return;
   u32 cap = n * 2 + 16, cnt = 0;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
-  int rc = ecl_hip_mul_batch(ctx->dev[0], ks, n, buf, cap, &cnt);
-  if (rc != ECL_OK) die_ecl(ctx, 0, rc, "mul_batch");
+  int rc = ecl_hip_mul_batch(ctx->dev[g], ks, n, buf, cap, &cnt);
+  if (rc != ECL_OK) die_ecl(ctx, g, rc, "mul_batch");
   for (u32 i = 0; i < cnt; ++i) {
     if (!list_confirm(ctx, buf[i].h160)) continue;
     sc pk;
@@ -527,10 +574,16 @@ static void mul_flush(ctx_t *ctx, u64 (*ks)[4], u32 n) {
   ctx_update(ctx, n);
 }
 /* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches.
-   The reference parses in its worker threads (main.c:503-527); here the GPU does the curve work, so the text side
-   must keep up with ~75 M scalars/s: stdin is read in 64 MB chunks cut at a line end, every chunk is counted and
-   parsed by a pool of threads (two passes: lines per slice, then parse into the final slots, order preserved),
-   and the device call for chunk i runs while chunk i+1 is being parsed.
+   The reference parses in its worker threads (main.c:503-527) and is bound by that; here the curve work is on the
+   GPUs, so the text side is a three-stage pipeline that keeps every stage busy:
+     reader thread   stdin -> 64 MB text chunks cut at a line end (ring of 3 buffers)
+     parse pool      a chunk is cut into slices at line ends; every slice is parsed by one thread into its own scratch
+                     (ONE pass; 64-digit lines - the normal input - decode 16 characters at a time with SSSE3), then
+                     the slices are packed into one scalar array, order preserved
+     device threads  one per GPU, each takes the next parsed array (`-t N` GPUs; the reference's worker queue,
+                     main.c:556-571)
+   `-bin` (not in the reference): stdin carries the scalars themselves, 32 bytes each (4 little-endian u64 = `fe`), for
+   feeders that can produce more than text parsing can take.
    Difference kept small on purpose: a line longer than 1024 characters is one line here (the reference's fgets
    splits it, main.c:552). */
 static signed char HEXVAL[256];
@@ -539,9 +592,33 @@ static void hexval_init(void) {
   for (int c = '0'; c <= '9'; ++c) HEXVAL[c] = (signed char)(c - '0');
   for (int c = 'a'; c <= 'f'; ++c) HEXVAL[c] = (signed char)(c - 'a' + 10), HEXVAL[c - 32] = (signed char)(c - 'a' + 10);
 }
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* 16 hex characters (most significant first) -> one little-endian u64; false if any character is not a hex digit */
+__attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out) {
+  const __m128i c = _mm_loadu_si128((const __m128i *)p);
+  const __m128i lower = _mm_or_si128(c, _mm_set1_epi8(0x20));
+  const __m128i isdig = _mm_and_si128(_mm_cmpgt_epi8(c, _mm_set1_epi8('0' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('9' + 1), c));
+  const __m128i isalp = _mm_and_si128(_mm_cmpgt_epi8(lower, _mm_set1_epi8('a' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('f' + 1), lower));
+  if (_mm_movemask_epi8(_mm_or_si128(isdig, isalp)) != 0xFFFF) return false;
+  const __m128i nib = _mm_add_epi8(_mm_and_si128(c, _mm_set1_epi8(0x0F)), _mm_and_si128(isalp, _mm_set1_epi8(9)));
+  const __m128i pair = _mm_maddubs_epi16(nib, _mm_set1_epi16(0x0110)); /* first digit * 16 + second digit */
+  const __m128i bytes = _mm_packus_epi16(pair, pair);                   /* 8 bytes, most significant first */
+  const __m128i rev = _mm_shuffle_epi8(bytes, _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7));
+  *out = (u64)_mm_cvtsi128_si64(rev);
+  return true;
+}
+static bool have_ssse3;
+#endif
 static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
   if (!ctx->raw_text) { /* fe_modn_from_hex: right to left, non-hex skipped, 64 digits at most */
+#if defined(__x86_64__)
+    if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
+        hex16_ssse3(p + 48, &k.w[0]))
+      return sc_reduce(k);
+    k = (sc){{0, 0, 0, 0}};
+#endif
     int cnt = 0;
     for (size_t i = len; i-- > 0 && cnt < 64;) {
       int v = HEXVAL[(u8)p[i]];
@@ -552,7 +629,7 @@ static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
     return sc_reduce(k);
   }
   u32 st[8];
-  sha256_host(st, (const u8 *)p, len);
+  sha256_stream(st, (const u8 *)p, len);
   k.w[0] = (u64)st[6] << 32 | st[7], k.w[1] = (u64)st[4] << 32 | st[5];
   k.w[2] = (u64)st[2] << 32 | st[3], k.w[3] = (u64)st[0] << 32 | st[1];
   return k;
@@ -560,9 +637,10 @@ static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
 typedef struct {
   const ctx_t *ctx;
   const char *buf;
-  size_t beg, end; /* slice [beg, end): starts at a line start, ends after a '\n' (or at the chunk end) */
-  u64 (*ks)[4];    /* NULL: count only */
-  size_t count, out;
+  size_t beg, end;   /* slice [beg, end): starts at a line start, ends after a '\n' (or at the chunk end) */
+  u64 (*tmp)[4];     /* this thread's scratch, grown on demand */
+  size_t tmp_cap, count;
+  u64 (*dst)[4];     /* second phase: where the slice's scalars go in the chunk's array */
 } parse_slice;
 static void *parse_worker(void *arg) {
   parse_slice *s = arg;
@@ -572,82 +650,183 @@ static void *parse_worker(void *arg) {
     size_t stop = nl ? (size_t)(nl - s->buf) : s->end, len = stop - at;
     if (len && s->buf[at + len - 1] == '\r') len--;
     if (len) {
-      if (s->ks) {
-        sc k = line_to_scalar(s->ctx, s->buf + at, len);
-        memcpy(s->ks[s->out + n], k.w, 32);
-      }
-      n++;
+      if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 32);
+      sc k = line_to_scalar(s->ctx, s->buf + at, len);
+      memcpy(s->tmp[n++], k.w, 32);
     }
     at = stop + 1;
   }
   s->count = n;
   return NULL;
 }
-typedef struct { ctx_t *ctx; u64 (*ks)[4]; size_t n; } mul_gpu_job;
-static void *mul_gpu_worker(void *arg) {
-  mul_gpu_job *j = arg;
+static void *pack_worker(void *arg) {
+  parse_slice *s = arg;
+  memcpy(s->dst, s->tmp, s->count * 32);
+  return NULL;
+}
+
+/* text chunks: reader thread -> parser */
+#define MUL_TEXT_CHUNK ((size_t)64 << 20)
+#define MUL_TEXT_RING 3
+typedef struct { char *buf; size_t len; } text_chunk;
+typedef struct {
+  text_chunk ring[MUL_TEXT_RING];
+  int head, tail, count; /* filled chunks: [tail, head) */
+  bool eof, bin;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+} text_queue;
+static void *mul_reader(void *arg) {
+  text_queue *q = arg;
+  char *carry = malloc(MUL_TEXT_CHUNK);
+  size_t have = 0;
+  for (;;) {
+    pthread_mutex_lock(&q->mu);
+    while (q->count == MUL_TEXT_RING) pthread_cond_wait(&q->cv, &q->mu);
+    text_chunk *c = &q->ring[q->head];
+    pthread_mutex_unlock(&q->mu);
+    memcpy(c->buf, carry, have);
+    size_t got;
+    while (have < MUL_TEXT_CHUNK && (got = fread(c->buf + have, 1, MUL_TEXT_CHUNK - have, stdin)) > 0) have += got;
+    bool eof = have < MUL_TEXT_CHUNK;
+    size_t end = have;
+    if (!eof) {
+      if (q->bin) end = have / 32 * 32;
+      else {
+        while (end > 0 && c->buf[end - 1] != '\n') end--;
+        if (end == 0) end = have; /* one line longer than the chunk: taken as it is */
+      }
+    }
+    memcpy(carry, c->buf + end, have - end);
+    c->len = end, have -= end;
+    pthread_mutex_lock(&q->mu);
+    if (end) q->head = (q->head + 1) % MUL_TEXT_RING, q->count++;
+    if (eof) q->eof = true;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+    if (eof) break;
+  }
+  free(carry);
+  return NULL;
+}
+/* parsed arrays: parser -> device threads */
+#define MUL_MAX_ARRAYS (MAX_GPUS + 2)
+typedef struct { u64 (*ks)[4]; size_t cap, n; } scalar_array;
+typedef struct {
+  ctx_t *ctx;
+  scalar_array arr[MUL_MAX_ARRAYS];
+  int narr;
+  int ready[MUL_MAX_ARRAYS], nready; /* indices waiting for a device */
+  int idle[MUL_MAX_ARRAYS], nidle;   /* indices free for the parser */
+  bool done;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+} scalar_queue;
+typedef struct { scalar_queue *q; int g; } mul_dev_arg;
+static void *mul_device_worker(void *arg) {
+  mul_dev_arg *a = arg;
+  scalar_queue *q = a->q;
   const size_t STEP = 1u << 22; /* scalars per device call */
-  for (size_t at = 0; at < j->n; at += STEP) mul_flush(j->ctx, j->ks + at, (u32)(j->n - at < STEP ? j->n - at : STEP));
+  for (;;) {
+    pthread_mutex_lock(&q->mu);
+    while (!q->nready && !q->done) pthread_cond_wait(&q->cv, &q->mu);
+    if (!q->nready) { pthread_mutex_unlock(&q->mu); break; }
+    int i = q->ready[0];
+    memmove(q->ready, q->ready + 1, sizeof(int) * --q->nready);
+    pthread_mutex_unlock(&q->mu);
+    scalar_array *ar = &q->arr[i];
+    if (q->ctx->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
+      for (size_t k = 0; k < ar->n; ++k)
+        printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)ar->ks[k][3], (unsigned long long)ar->ks[k][2],
+               (unsigned long long)ar->ks[k][1], (unsigned long long)ar->ks[k][0]);
+    } else
+      for (size_t at = 0; at < ar->n; at += STEP) mul_flush(q->ctx, a->g, ar->ks + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
+    pthread_mutex_lock(&q->mu);
+    q->idle[q->nidle++] = i;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+  }
   return NULL;
 }
 static void cmd_mul(ctx_t *ctx) {
   ctx->ts_started = tsnow();
   hexval_init();
-  const size_t CHUNK = 64u << 20;
+#if defined(__x86_64__)
+  have_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   int P = (int)(ncpu < 1 ? 1 : ncpu > 32 ? 32 : ncpu);
-  char *buf = malloc(CHUNK + MAX_LINE_SIZE * 64);
-  size_t have = 0;
-  u64(*ks[2])[4] = {NULL, NULL};
-  size_t cap[2] = {0, 0};
-  pthread_t gpu_thread;
-  mul_gpu_job gjob;
-  bool gpu_busy = false;
-  int cur = 0;
-  bool eof = false;
-  while (!eof || have) {
-    size_t got = eof ? 0 : fread(buf + have, 1, CHUNK - have, stdin);
-    if (got == 0) eof = true;
-    have += got;
-    if (!have) break;
-    /* cut at the last line end; at EOF take everything */
-    size_t end = have;
-    if (!eof) {
-      while (end > 0 && buf[end - 1] != '\n') end--;
-      if (end == 0) { /* one line longer than the chunk: grow is not worth it, treat what we have as a line */
-        end = have;
+  text_queue tq;
+  memset(&tq, 0, sizeof tq);
+  tq.bin = ctx->bin_input;
+  pthread_mutex_init(&tq.mu, NULL), pthread_cond_init(&tq.cv, NULL);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].buf = malloc(MUL_TEXT_CHUNK);
+  scalar_queue sq;
+  memset(&sq, 0, sizeof sq);
+  sq.ctx = ctx, sq.narr = ctx->ngpus + 2;
+  pthread_mutex_init(&sq.mu, NULL), pthread_cond_init(&sq.cv, NULL);
+  for (int i = 0; i < sq.narr; ++i) sq.idle[sq.nidle++] = i;
+  pthread_t reader, devth[MAX_GPUS];
+  mul_dev_arg dargs[MAX_GPUS];
+  pthread_create(&reader, NULL, mul_reader, &tq);
+  for (int g = 0; g < ctx->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
+  parse_slice sl[32];
+  memset(sl, 0, sizeof sl);
+  for (;;) {
+    pthread_mutex_lock(&tq.mu);
+    while (!tq.count && !tq.eof) pthread_cond_wait(&tq.cv, &tq.mu);
+    if (!tq.count) { pthread_mutex_unlock(&tq.mu); break; }
+    text_chunk *c = &tq.ring[tq.tail];
+    pthread_mutex_unlock(&tq.mu);
+    /* an array for this chunk's scalars */
+    pthread_mutex_lock(&sq.mu);
+    while (!sq.nidle) pthread_cond_wait(&sq.cv, &sq.mu);
+    int ai = sq.idle[--sq.nidle];
+    pthread_mutex_unlock(&sq.mu);
+    scalar_array *ar = &sq.arr[ai];
+    if (ctx->bin_input) {
+      ar->n = c->len / 32;
+      if (ar->n > ar->cap) free(ar->ks), ar->ks = malloc(ar->n * 32), ar->cap = ar->n;
+      memcpy(ar->ks, c->buf, ar->n * 32);
+    } else {
+      pthread_t th[32];
+      int ns = 0;
+      size_t at = 0, end = c->len;
+      for (int i = 0; i < P && at < end; ++i) { /* slices at line boundaries */
+        size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
+        if (stop <= at) stop = at + 1;
+        while (stop < end && c->buf[stop - 1] != '\n') stop++;
+        sl[ns].ctx = ctx, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
+        at = stop, ns++;
       }
+      for (int i = 0; i < ns; ++i) pthread_create(&th[i], NULL, parse_worker, &sl[i]);
+      size_t total = 0;
+      for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL), total += sl[i].count;
+      if (total > ar->cap) free(ar->ks), ar->ks = malloc(total * 32), ar->cap = total;
+      ar->n = total;
+      size_t off = 0;
+      for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count, pthread_create(&th[i], NULL, pack_worker, &sl[i]);
+      for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL);
     }
-    /* slices at line boundaries */
-    parse_slice sl[32];
-    pthread_t th[32];
-    int ns = 0;
-    size_t at = 0;
-    for (int i = 0; i < P && at < end; ++i) {
-      size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
-      if (stop <= at) stop = at + 1;
-      while (stop < end && buf[stop - 1] != '\n') stop++;
-      sl[ns] = (parse_slice){ctx, buf, at, stop, NULL, 0, 0};
-      at = stop, ns++;
-    }
-    for (int i = 0; i < ns; ++i) pthread_create(&th[i], NULL, parse_worker, &sl[i]);
-    size_t total = 0;
-    for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL), sl[i].out = total, total += sl[i].count;
-    if (total > cap[cur]) free(ks[cur]), ks[cur] = malloc(total * 32), cap[cur] = total;
-    for (int i = 0; i < ns; ++i) sl[i].ks = ks[cur], pthread_create(&th[i], NULL, parse_worker, &sl[i]);
-    for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL);
-    /* hand the parsed chunk to the GPU thread, keep parsing the next one meanwhile */
-    if (gpu_busy) pthread_join(gpu_thread, NULL);
-    gjob = (mul_gpu_job){ctx, ks[cur], total};
-    pthread_create(&gpu_thread, NULL, mul_gpu_worker, &gjob);
-    gpu_busy = true;
-    cur ^= 1;
-    memmove(buf, buf + end, have - end);
-    have -= end;
+    pthread_mutex_lock(&tq.mu); /* the text buffer goes back to the reader */
+    tq.tail = (tq.tail + 1) % MUL_TEXT_RING, tq.count--;
+    pthread_cond_broadcast(&tq.cv);
+    pthread_mutex_unlock(&tq.mu);
+    pthread_mutex_lock(&sq.mu);
+    sq.ready[sq.nready++] = ai;
+    pthread_cond_broadcast(&sq.cv);
+    pthread_mutex_unlock(&sq.mu);
   }
-  if (gpu_busy) pthread_join(gpu_thread, NULL);
-  free(buf), free(ks[0]), free(ks[1]);
-  ctx_finish(ctx);
+  pthread_mutex_lock(&sq.mu);
+  sq.done = true;
+  pthread_cond_broadcast(&sq.cv);
+  pthread_mutex_unlock(&sq.mu);
+  pthread_join(reader, NULL);
+  for (int g = 0; g < ctx->ngpus; ++g) pthread_join(devth[g], NULL);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].buf);
+  for (int i = 0; i < sq.narr; ++i) free(sq.arr[i].ks);
+  for (int i = 0; i < 32; ++i) free(sl[i].tmp);
+  if (!ctx->parse_only) ctx_finish(ctx);
 }
 
 /* ------------------------------------------------------------------------------------------- rnd */
@@ -817,6 +996,7 @@ static void usage(const char *name) { /* main.c:750-772 */
   printf("  -d <offs:size>  - bit offset and size for search (example: 128:32, default: 0:32)\n");
   printf("  -q              - quiet mode (no output to stdout; -o required)\n");
   printf("  -endo           - use endomorphism (default: false)\n");
+  printf("  -bin            - mul: stdin carries 32-byte little-endian scalars instead of hex lines\n");
   printf("\nOther commands:\n");
   printf("  blf-gen         - create bloom filter from list of hex-encoded hash160\n");
   printf("  blf-check       - check bloom filter for given hex-encoded hash160\n");
@@ -939,6 +1119,18 @@ static int run_bench(args_t *args) {
   return 0;
 }
 
+typedef struct { ctx_t *ctx; int g, device; u32 flags; u64 share; int rc; } open_job;
+static void *open_worker(void *arg) {
+  open_job *j = arg;
+  ctx_t *ctx = j->ctx;
+  int rc = ecl_hip_open(&ctx->dev[j->g], j->device, j->flags, ctx->cmd == CMD_MUL ? 0 : ctx->ord_offs);
+  if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx->dev[j->g], ctx->blf.bits, ctx->blf.size);
+  if (rc == ECL_OK && ctx->list) rc = ecl_hip_set_list(ctx->dev[j->g], (const uint32_t(*)[5])ctx->list, ctx->list_count);
+  if (rc == ECL_OK && j->share) rc = ecl_hip_reserve(ctx->dev[j->g], j->share, 4096);
+  j->rc = rc;
+  return NULL;
+}
+
 int main(int argc, const char **argv) {
   setlocale(LC_NUMERIC, "");
   args_t args = {argc, argv};
@@ -947,6 +1139,13 @@ int main(int argc, const char **argv) {
     if (!strcmp(argv[1], "blf-gen")) return blf_gen(&args), 0;
     if (!strcmp(argv[1], "blf-check")) return blf_check(&args), 0;
     if (!strcmp(argv[1], "bench")) return run_bench(&args);
+    if (!strcmp(argv[1], "parse")) { /* hidden: `mul`'s text front end alone (no GPU), for the parser tests */
+      ctx.cmd = CMD_MUL, ctx.parse_only = true, ctx.ngpus = 1;
+      ctx.raw_text = args_bool(&args, "-raw"), ctx.bin_input = args_bool(&args, "-bin");
+      pthread_mutex_init(&ctx.lock, NULL);
+      cmd_mul(&ctx);
+      return 0;
+    }
     if (!strcmp(argv[1], "add")) ctx.cmd = CMD_ADD;
     if (!strcmp(argv[1], "mul")) ctx.cmd = CMD_MUL;
     if (!strcmp(argv[1], "rnd")) ctx.cmd = CMD_RND;
@@ -973,6 +1172,7 @@ int main(int argc, const char **argv) {
   if (!ctx.a33 && !ctx.a65) ctx.a33 = true;
   ctx.endo = args_bool(&args, "-endo") && ctx.cmd != CMD_MUL;
   ctx.raw_text = args_bool(&args, "-raw");
+  ctx.bin_input = args_bool(&args, "-bin") && ctx.cmd == CMD_MUL;
   pthread_mutex_init(&ctx.lock, NULL);
   ctx.ts_started = ctx.ts_updated = tsnow();
   ctx.ts_printed = ctx.ts_started - 5000;
@@ -988,27 +1188,37 @@ int main(int argc, const char **argv) {
   u64 want = args_uint(&args, "-t", (u64)have);
   ctx.ngpus = (int)(want < 1 ? 1 : want > (u64)have ? (u64)have : want);
   if (ctx.ngpus > MAX_GPUS) ctx.ngpus = MAX_GPUS;
-  if (ctx.cmd == CMD_MUL) ctx.ngpus = 1;
-  u32 flags = (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0);
-  for (int g = 0; g < ctx.ngpus; ++g) {
-    int rc = ecl_hip_open(&ctx.dev[g], g % real, flags, ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
-    if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx.dev[g], ctx.blf.bits, ctx.blf.size);
-    if (rc == ECL_OK && ctx.list) rc = ecl_hip_set_list(ctx.dev[g], (const uint32_t(*)[5])ctx.list, ctx.list_count);
-    if (rc == ECL_OK && ctx.cmd != CMD_MUL) {
-      /* walk buffers of this device's share of the scan, before the clock of the status line starts */
-      u64 share = 1ull << 32;
-      if (ctx.cmd == CMD_RND) {
-        share = (ctx.ord_size < 32 ? 1ull << (ctx.ord_size < 21 ? 21 : ctx.ord_size) : 1ull << 32) / (u64)ctx.ngpus;
-      } else {
-        sc span;
-        sc_subraw(&span, &ctx.range_e, &ctx.range_s);
-        for (u32 i = 0; i < ctx.ord_offs && i < 256; ++i) span = sc_shr1(span);
-        if (!(span.w[1] | span.w[2] | span.w[3]) && span.w[0] / (u64)ctx.ngpus + 4096 < share) share = span.w[0] / (u64)ctx.ngpus + 4096;
+  /* Device bring-up, all GPUs at once (one host thread each): context, filter upload from the one pinned host copy
+     (every GPU over its own PCIe link), optional list, and the walk buffers of the chunks this scan will hand out -
+     all before the clock of the status line starts; the time it took is printed in the banner. */
+  u64 t_setup0 = tsnow();
+  bool pinned = ctx.blf.size >= (8u << 20) && ecl_hip_pin_host(ctx.blf.bits, ctx.blf.size * 8) == ECL_OK;
+  {
+    pthread_t th[MAX_GPUS];
+    open_job jobs[MAX_GPUS];
+    u64 share = 0;
+    if (ctx.cmd != CMD_MUL) {
+      /* keys of the largest device call: see scan_chunk() */
+      sc hashed;
+      if (ctx.cmd == CMD_RND) hashed = sc_u64(1ull << (ctx.ord_size < 21 ? 21 : ctx.ord_size > 62 ? 62 : ctx.ord_size));
+      else {
+        sc_subraw(&hashed, &ctx.range_e, &ctx.range_s);
+        for (u32 i = 0; i < ctx.ord_offs && i < 256; ++i) hashed = sc_shr1(hashed);
+        hashed = sc_add_u64_raw(hashed, 4096);
       }
-      rc = ecl_hip_reserve(ctx.dev[g], share ? share : 1, 4096);
+      share = scan_chunk(&ctx, &hashed);
+      if (!(hashed.w[1] | hashed.w[2] | hashed.w[3]) && hashed.w[0] < share) share = hashed.w[0];
     }
-    if (rc != ECL_OK) die_ecl(&ctx, g, rc, "open");
+    for (int g = 0; g < ctx.ngpus; ++g) {
+      jobs[g] = (open_job){&ctx, g, g % real, (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0), share, ECL_OK};
+      pthread_create(&th[g], NULL, open_worker, &jobs[g]);
+    }
+    for (int g = 0; g < ctx.ngpus; ++g) pthread_join(th[g], NULL);
+    for (int g = 0; g < ctx.ngpus; ++g)
+      if (jobs[g].rc != ECL_OK) die_ecl(&ctx, g, jobs[g].rc, "open");
   }
+  if (pinned) ecl_hip_unpin_host(ctx.blf.bits);
+  double setup_s = (tsnow() - t_setup0) / 1000.0;
   printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", ctx.ngpus, ctx.a33, ctx.a65, ctx.endo);
   if (ctx.list) printf("list (%'llu)\n", (unsigned long long)ctx.list_count);
   else printf("bloom\n");
@@ -1016,6 +1226,8 @@ int main(int argc, const char **argv) {
     printf("range_s: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_s.w[3], (unsigned long long)ctx.range_s.w[2], (unsigned long long)ctx.range_s.w[1], (unsigned long long)ctx.range_s.w[0]);
     printf("range_e: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_e.w[3], (unsigned long long)ctx.range_e.w[2], (unsigned long long)ctx.range_e.w[1], (unsigned long long)ctx.range_e.w[0]);
   }
+  printf("setup: %.2fs (%d device%s opened in parallel, %.0f MB filter uploaded, walk buffers reserved)\n", setup_s, ctx.ngpus,
+         ctx.ngpus == 1 ? "" : "s", ctx.blf.size * 8 / 1e6);
   printf("----------------------------------------\n");
   fflush(stdout);
   signal(SIGINT, handle_sigint);

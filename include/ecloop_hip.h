@@ -75,6 +75,12 @@ void ecl_hip_close(ecl_hip *h);
    filter built from a hash list, utils.c:277-280) into HBM.  May be called again to replace the filter. */
 int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 
+/* Optional: page-lock a host buffer (e.g. the bits about to be given to ecl_hip_set_bloom on several devices) so that
+   the uploads run by DMA at PCIe rate, concurrently from one buffer; undo with ecl_hip_unpin_host.  Thin wrappers of
+   hipHostRegister / hipHostUnregister so that a plain-C host needs no HIP headers. */
+int ecl_hip_pin_host(const void *p, size_t bytes);
+int ecl_hip_unpin_host(const void *p);
+
 /* blf_add (utils.c:290-306) in bulk: set the 20 bits of each of n hash160 values (h160_t words) in the resident
    filter; ecl_hip_get_bloom copies the bit array back (e.g. to write a .blf file, utils.c:328-360). */
 int ecl_hip_bloom_insert(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
@@ -119,6 +125,13 @@ int ecl_hip_get_geometry(ecl_hip *h, uint32_t *half_group, uint32_t *lanes);
 /* Measurement: accumulated HIP-event time of the main add kernel since the last reset, and launch count. */
 int ecl_hip_get_timing(ecl_hip *h, double *kernel_ms, uint64_t *launches, uint64_t *keys);
 int ecl_hip_reset_timing(ecl_hip *h);
+/* ... of the set-up a non-contiguous ecl_hip_add_range pays before its search kernel (base centre through the window
+   table, lane centres; HIP events on the handle's stream), and how many calls paid it; contiguous follow-up calls
+   pay nothing.  Reset by ecl_hip_reset_timing. */
+int ecl_hip_get_setup_timing(ecl_hip *h, double *setup_ms, uint64_t *setups);
+/* ... of ecl_hip_mul_batch: HIP-event time from the first chunk's copy being awaited to the last kernel (host->device
+   copies overlapped with the kernels), calls and scalars since the last reset. */
+int ecl_hip_get_mul_timing(ecl_hip *h, double *ms, uint64_t *calls, uint64_t *scalars);
 
 /* Known-answer test of the device code (hash160 of 1*G, 2*G, 0xdc2a04*G, both encodings, via the double-and-add
    kernel) and a cross-check of the walk kernel against it over 4096 consecutive keys.  ecl_hip_open() runs it

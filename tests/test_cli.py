@@ -221,3 +221,70 @@ def test_pause_resume_keys(cli, tmp_path):
     assert "pause" not in final and "resume" not in final
     secs = float(final.split("s ~")[0])
     assert secs < time.time() - t_start - 1.5  # the two paused seconds are not in the reported time
+
+
+# ---- `mul` text front end (no GPU): the hidden `parse` command prints the scalars the device threads would get
+
+
+def _parse(cli, data, *flags):
+    pr = subprocess.run([cli, "parse", *flags], input=data, stdout=subprocess.PIPE, check=True, timeout=300)
+    return pr.stdout.decode().split()
+
+
+def test_mul_parser_hex_lines_match_fe_modn_from_hex(cli):
+    """fe_modn_from_hex (lib/ecc.c:81-95,262-265) on every kind of line: the 64-digit fast path (SSSE3), upper case,
+    short / over-long values, prefixes and junk characters (skipped), values >= n (reduced), CRLF, empty lines"""
+    import random
+    import orc
+    r = random.Random(5)
+    lines = []
+    for _ in range(30000):
+        t = r.random()
+        if t < 0.6:
+            l = "%064x" % r.getrandbits(256)
+        elif t < 0.7:
+            l = ("%064x" % r.getrandbits(256)).upper()
+        elif t < 0.75:
+            l = "%x" % r.getrandbits(r.randrange(1, 300))
+        elif t < 0.8:
+            l = "0x" + "%064x" % r.getrandbits(256)
+        elif t < 0.85:
+            l = "zz%062xgg" % r.getrandbits(200)
+        elif t < 0.88:
+            l = "f" * 64
+        elif t < 0.92:
+            l = "%064x" % (orc.N + r.randrange(-3, 3))
+        elif t < 0.95:
+            l = ""
+        else:
+            l = "".join(r.choice("0123456789abcdefXYZ -") for _ in range(r.randrange(1, 100)))
+        lines.append(l)
+    want = ["%064x" % orc.sn_from_hex(l) for l in lines if l]
+    assert _parse(cli, ("\n".join(lines) + "\n").encode()) == want
+    assert _parse(cli, ("\r\n".join(lines)).encode()) == want  # CRLF, no newline at the end
+
+
+def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
+    """-raw = SHA-256 of the line (main.c:505-527) for lengths around the padding boundaries; -bin passes 32-byte
+    little-endian scalars through; an input of several 64 MB chunks keeps every line, in order"""
+    import random
+    r = random.Random(9)
+    words = ["".join(r.choice("abcdefghijklmnopqrstuvwxyz0123456789 !") for _ in range(n)) for n in
+             list(range(1, 200)) + [r.randrange(1, 1000) for _ in range(300)]]
+    got = _parse(cli, ("\n".join(words) + "\n").encode(), "-raw")
+    assert got == [hashlib.sha256(w.encode()).hexdigest() for w in words]
+    ks = [r.getrandbits(256) for _ in range(5000)]
+    raw = b"".join(k.to_bytes(32, "little") for k in ks)
+    assert _parse(cli, raw, "-bin") == ["%064x" % k for k in ks]
+    n = 2_300_000  # 65 bytes per line -> 150 MB: three text chunks
+    blob = np.frombuffer(np.random.default_rng(3).bytes(n * 32), dtype=np.uint8)
+    hexd = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
+    text = np.empty((n, 65), dtype=np.uint8)
+    b = blob.reshape(n, 32)
+    text[:, 0:64:2], text[:, 1:64:2], text[:, 64] = hexd[b >> 4], hexd[b & 15], 10
+    out = _parse(cli, text.tobytes())
+    assert len(out) == n
+    N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    for i in list(range(0, n, 9973)) + [n - 1, 1032444, 1032445, 1032446]:
+        v = int.from_bytes(b[i].tobytes(), "big")
+        assert int(out[i], 16) == (v - N if v >= N else v), i

@@ -1,0 +1,53 @@
+"""bench.py on the GPU box: the JSON contract at N=1, and the N>1 code path with two ranks - over RCCL when two GPUs
+are visible, else two ranks sharing the one GPU over gloo (ECL_BENCH_SHARE_GPU=1), so the sharded legs, the barrier /
+MAX-over-ranks timing and the planted-key checks of every rank run either way."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(out):
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert lines, out.decode(errors="replace")[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_single_gpu_small():
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--keys-log2", "28", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
+    r = last_json(pr.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["config"]["planted_checked"] == 16 and r["value"] > 1000
+    assert abs(r["value"] - (1 << 28) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3
+    rf = r["roofline"]
+    assert rf["bound"] == "valu-int32" and rf["ms_per_launch"] > 0 and rf["keys_per_launch"] == 1 << 28
+    assert rf["static"] and rf["static"]["kernel_valu"] > 3000  # instruction mix of the library that was timed
+    if rf.get("profile"):
+        assert "matches_build" in rf["profile"] and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=2e-3)
+
+
+def test_bench_two_ranks_strong_and_weak_legs():
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not two:
+        env["ECL_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--keys-log2", "27", "--steps", "2", "--warmup", "1"]
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, cwd=ROOT, env=env)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    r = last_json(pr.stdout)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["keys_per_gpu_per_step"] == 1 << 26
+    assert abs(r["value"] - (1 << 27) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3
+    w = r["weak_scaling"]
+    assert w["keys_per_gpu_per_step"] == 1 << 27 and abs(w["value"] - 2 * (1 << 27) / (w["ms_per_step"] * 1e3)) / w["value"] < 1e-3
+    assert "cpu_baseline" not in r  # rank 0 at N=1 only

@@ -1,32 +1,80 @@
 #!/bin/bash
-# Collects the evidence under profiles/ on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/prof/{bench.json, stats.txt, pmc_*.csv}
-# Counter passes are separate runs with --kernel-trace only (no sys/hip/hsa tracing together with --pmc).
+# Collects the measured evidence of one round on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh [round-tag, default r02]
+# -> gpurun_out/prof_<tag>/{bench.json, stats.txt, pmc.txt, calib.txt, ubench8.txt, ubench4.txt, <tag>_roofline.json}
+# Counter passes are separate runs with --kernel-trace only (never --pmc together with sys/hip/hsa tracing), one
+# 2^32-key launch each (ECL_HIP_SKIP_SELFTEST=1: no 4096-key self-test launch in the counters).
+# Copy what is to be kept into profiles/ (tracked); bench.py reads profiles/<tag>_roofline.json.
 set -u
+TAG=${1:-r02}
 export TMPDIR=/tmp
 R=$(pwd)
-O=$R/gpurun_out/prof
+O=$R/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
-python bench.py > "$O/bench.json" 2> "$O/bench.err"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+T=ecloop_amd/csrc/tools
+[ -x $T/ubench ] || $HIPCC --offload-arch=gfx950 -O3 $T/ubench.hip -o $T/ubench
+[ -x $T/fetch_calib ] || $HIPCC --offload-arch=gfx950 -O3 $T/fetch_calib.hip -o $T/fetch_calib
+$T/ubench 8 > "$O/ubench8.txt" 2>&1
+$T/ubench 4 > "$O/ubench4.txt" 2>&1
+
 cd /tmp
+# per-kernel time of the default bench command
 rocprofv3 --kernel-trace --stats -d "$O/stats" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu > "$O/stats.log" 2>&1
 db=$(find "$O/stats" -name '*.db' | head -1)
 [ -n "$db" ] && python "$R/tools/rocprof_summary.py" "$db" > "$O/stats.txt"
+rm -rf "$O/stats"
+
+summ() {  # counter csv (+ kernel trace csv) of one pass -> "COUNTER sum dispatches" lines for kernels matching $2
+python - "$1" "$2" <<'PY'
+import csv, glob, os, sys, collections
+d, pat = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(float); n = collections.Counter()
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat not in r["Kernel_Name"]: continue
+        key = (r["Kernel_Name"].split("(")[0][:60], r["Counter_Name"])
+        acc[key] += float(r["Counter_Value"]); n[key] += 1
+for (k, c) in sorted(acc): print("PMC %s %s %.0f %d" % (k.replace(" ", ""), c, acc[(k, c)], n[(k, c)]))
+for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat not in r["Kernel_Name"]: continue
+        print("TRACE %s %d" % (r["Kernel_Name"].split("(")[0][:60].replace(" ", ""), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+PY
+}
+
+: > "$O/pmc.txt"
 i=0
 for set in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD" \
-           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE" "VALUBusy" "VALUUtilization"; do
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_THREAD_CYCLES_VALU" \
+           "FETCH_SIZE" "WRITE_SIZE" "VALUBusy" "VALUUtilization"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmc$i" -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu > "$O/pmc$i.log" 2>&1
-  f=$(find "$O/pmc$i" -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && python - "$f" > "$O/pmc$i.txt" <<'PY'
-import csv, sys, collections
-acc = collections.defaultdict(float); n = collections.Counter()
-for r in csv.DictReader(open(sys.argv[1])):
-    if "k_add" not in r["Kernel_Name"]: continue
-    acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-for k in sorted(acc): print("%-24s %d   (dispatches %d)" % (k, acc[k], n[k])) if acc[k] > 1000 else print("%-24s %.3f   (sum over %d dispatches)" % (k, acc[k], n[k]))
-PY
+  ECL_HIP_SKIP_SELFTEST=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmc$i" -o p -- python "$R/bench.py" --steps 1 --warmup 0 --no-cpu > "$O/pmc$i.log" 2>&1
+  echo "# pass $i: --pmc $set" >> "$O/pmc.txt"
+  summ "$O/pmc$i" k_add >> "$O/pmc.txt"
   rm -rf "$O/pmc$i"
 done
-rm -rf "$O/stats"
-cd "$R"; cat "$O"/bench.json; cat "$O"/stats.txt | head -8; cat "$O"/pmc*.txt
+
+# FETCH_SIZE / WRITE_SIZE against known byte counts in the kernel's two access patterns
+: > "$O/calib.txt"
+for set in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/cal_$set" -o c -- "$R/$T/fetch_calib" > "$O/cal_$set.log" 2>&1
+  echo "# --pmc $set" >> "$O/calib.txt"
+  grep '^CALIB' "$O/cal_$set.log" >> "$O/calib.txt"
+  python - "$O/cal_$set" >> "$O/calib.txt" <<'PY'
+import csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+    for r in rows:
+        print("PMCROW %s %s %s" % (r["Kernel_Name"].split("(")[0], r["Counter_Name"], r["Counter_Value"]))
+PY
+  rm -rf "$O/cal_$set"
+done
+
+cd "$R"
+python tools/make_roofline_profile.py "$O" "$TAG" > "$O/${TAG}_roofline.json" 2> "$O/make_profile.err"
+# the final bench line, priced with the profile just taken
+cp "$O/${TAG}_roofline.json" "profiles/${TAG}_roofline.json"
+python bench.py > "$O/bench.json" 2> "$O/bench.err"
+cat "$O/bench.json"; head -8 "$O/stats.txt"; cat "$O/pmc.txt" "$O/calib.txt"; cat "$O/make_profile.err"

@@ -34,6 +34,8 @@ def run(cmd, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--endo-log2", type=int, default=28)
+    ap.add_argument("--filter-n", type=int, default=bench.FILTER_N, help="1100000000: the ~6 GB filter of configs[2] (random fill at the design density)")
+    ap.add_argument("--main-log2", type=int, default=32)
     a = ap.parse_args()
     ref = os.path.join(ROOT, "oracle", "_ref", "ecloop_sane")
     cli = build_host_cli()
@@ -42,12 +44,12 @@ def main():
     atexit.register(shutil.rmtree, tmp, ignore_errors=True)
     blf = os.path.join(tmp, "bench.blf")
     d = Device(0)
-    size, offs, _ = bench.build_filter(d, bench.RANGE_A, 1 << 32)
+    size, offs, _ = bench.build_filter(d, bench.RANGE_A, 1 << 32, a.filter_n)
     blf_save(blf, d.get_bloom(size))
     d.close()
-    rep = ["# tools/full_range_parity.py: HIP path vs the reference binary, same .blf (%d words, 10^7 entries + %d planted keys)" % (size, len(offs))]
+    rep = ["# tools/full_range_parity.py: HIP path vs the reference binary, same .blf file (%d words = %.0f MB, %d entries + %d planted keys)" % (size, size * 8 / 1e6, a.filter_n, len(offs))]
     threads = str(min(os.cpu_count() or 1, 64))
-    legs = [("add addr33, 2^32 keys", [], 32), ("add -a cu -endo, 2^%d keys" % a.endo_log2, ["-a", "cu", "-endo"], a.endo_log2)]
+    legs = [("add addr33, 2^%d keys" % a.main_log2, [], a.main_log2), ("add -a cu -endo, 2^%d keys" % a.endo_log2, ["-a", "cu", "-endo"], a.endo_log2)]
     ok = True
     for name, extra, lg in legs:
         rng = "%x:%x" % (bench.RANGE_A, bench.RANGE_A + (1 << lg) - 1)
@@ -61,10 +63,11 @@ def main():
                 "identical : %s" % same]
         if not same:
             rep += ["only HIP: %s" % sorted(set(g) - set(r))[:5], "only reference: %s" % sorted(set(r) - set(g))[:5]]
-        if lg == 32:
+        if not extra:
             rep += ["lines:"] + ["  " + l for l in g]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    open(os.path.join(ROOT, "gpurun_out", "full_range_parity.txt"), "w").write("\n".join(rep) + "\n")
+    name = "full_range_parity.txt" if a.filter_n == bench.FILTER_N else "full_range_parity_%dM.txt" % (a.filter_n // 1000000)
+    open(os.path.join(ROOT, "gpurun_out", name), "w").write("\n".join(rep) + "\n")
     print("\n".join(rep))
     sys.exit(0 if ok else 1)
 

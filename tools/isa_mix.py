@@ -1,52 +1,179 @@
 #!/usr/bin/env python3
-"""Instruction mix of k_add<addr33> from the gfx950 assembly (hipcc -save-temps): VALU instructions per basic block,
-split into the issue classes the microbenchmark (profiles/ubench_r01.txt) prices differently:
-  mad64 : v_mad_u64_u32                                   4.61 SIMD-cycles per wave-instruction (nominal clock)
-  fast  : VOP2-encoded add / sub / and / or / xor / mov   2.55
-  other : every other VALU instruction                    4.23
-usage: tools/isa_mix.py path/to/ecloop_hip-hip-amdgcn-amd-amdhsa-gfx950.s [mangled kernel name]"""
+"""Static instruction mix of the add kernel from the gfx950 assembly the build keeps next to the library
+(ecloop_amd/libecloop_hip.gfx950.s, written by ecloop_amd/build.py with -save-temps: the assembly OF the shipped
+code object, not a second compilation).
+
+The compiler annotates every basic block with the loop it belongs to, so the blocks can be attributed to the loop
+nest of k_add (add_kernel.h): launch loop > {prefix-product loop, table loop > `which` loop > probe loop}.
+VALU instructions are split into the issue classes the microbenchmark (ecloop_amd/csrc/tools/ubench.hip ->
+profiles/ubench_r02.txt) prices differently:
+  mad64 : v_mad_u64_u32
+  fast  : add / sub / and / or / xor / mov / not and v_bitop3_b32 - the opcodes that reach ~2.3-2.5 SIMD-cycles per
+          wave64 instruction in long runs (and ~4.2 when single between other instructions)
+  other : every other VALU instruction (rotates, shifts, v_add3, v_perm, multiplies, carries, selects, ...): >= 4.1
+What the numbers are used for:
+  * `fingerprint`: bench.py puts it into its JSON line and compares it with the one stored in
+    profiles/r02_roofline.json (the PMC counters in that file belong to a particular build); the CPU test
+    tests/test_profiles_fresh.py fails when a freshly built library drifts more than 1 % from it;
+  * `per_key_static`: one trip of the `which` loop (one key; this includes its rarely executed candidate-ring
+    blocks, so it is an UPPER estimate) + half a trip of the table loop around it and of the prefix-product loop
+    (each serves two keys).  The PMC count SQ_INSTS_VALU is the truth for the total; the class SHARES come from here.
+
+usage: tools/isa_mix.py [file.s] [mangled kernel name] [--json]"""
+import json
+import os
 import re
 import sys
 
-COST = {"mad64": 4.61, "fast": 2.55, "other": 4.23}
-FAST = {"v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32",
-        "v_mov_b32_e32", "v_add_u32_e64"}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASM = os.path.join(ROOT, "ecloop_amd", "libecloop_hip.gfx950.s")
+K_ADD33 = "_Z5k_addILb1ELb0ELb0EEv8add_args"
+FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_not_b32", "v_bitop3_b32"}
+KEYS = ("valu", "mad64", "fast", "other", "salu", "smem", "vmem", "lds", "scratch")
 
 
 def classify(op):
-    if op == "v_mad_u64_u32":
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if base == "v_mad_u64_u32":
         return "mad64"
-    return "fast" if op in FAST else "other"
+    return "fast" if base in FAST else "other"
+
+
+def zero():
+    return {k: 0 for k in KEYS}
+
+
+def add_to(c, op):
+    if op.startswith("v_"):
+        c["valu"] += 1
+        c[classify(op)] += 1
+    elif op.startswith("scratch_"):
+        c["scratch"] += 1
+    elif op.startswith(("global_", "buffer_", "flat_")):
+        c["vmem"] += 1
+    elif op.startswith("ds_"):
+        c["lds"] += 1
+    elif op.startswith(("s_load", "s_buffer_load")):
+        c["smem"] += 1
+    elif op.startswith("s_"):
+        c["salu"] += 1
 
 
 def blocks(path, kernel):
+    """-> list of {label, header, depth, counts}: the basic blocks of `kernel` with the innermost loop they are in"""
     s = open(path).read()
-    a = s.index(kernel + ":")
+    a = s.index("\n" + kernel + ":")
     b = s.index(".Lfunc_end", a)
-    out, cur, name = [], {"mad64": 0, "fast": 0, "other": 0}, "entry"
-    for line in s[a:b].split("\n")[1:]:
-        line = line.strip()
-        m = re.match(r"(\.LBB\d+_\d+):", line)
-        br = re.match(r"s_cbranch_\w+|s_branch|s_endpgm", line)
-        if m or br:
-            if sum(cur.values()):
-                out.append((name, cur))
-            cur = {"mad64": 0, "fast": 0, "other": 0}
-            if m:
-                name = m.group(1)
-            continue
-        m = re.match(r"(v_[a-z0-9_]+)", line)
+    out = []
+    cur = {"label": "entry", "header": None, "depth": 0, "c": zero()}
+    lines = s[a:b].split("\n")[2:]
+    i = 0
+    while i < len(lines):
+        line = lines[i]
+        m = re.match(r"(\.LBB\d+_\d+):|; %bb\.(\d+):", line)
         if m:
-            cur[classify(m.group(1))] += 1
-    if sum(cur.values()):
-        out.append((name, cur))
-    return out
+            out.append(cur)
+            label = m.group(1) or ("bb." + m.group(2))
+            cur = {"label": label, "header": None, "depth": 0, "c": zero()}
+            # the loop comments of this block: on this line and the comment-only lines that follow
+            j, text = i, line
+            while j + 1 < len(lines) and re.match(r"\s+;", lines[j + 1]):
+                j += 1
+                text += "\n" + lines[j]
+            mm = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", text)
+            if mm:
+                cur["header"], cur["depth"] = label.lstrip(".L"), int(mm.group(1))
+            else:
+                mm = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", text)
+                if mm:
+                    cur["header"], cur["depth"] = mm.group(1), int(mm.group(2))
+            i = j + 1
+            continue
+        mm = re.match(r"\s+([a-z][a-z0-9_]+)", line)
+        if mm:
+            add_to(cur["c"], mm.group(1))
+        i += 1
+    out.append(cur)
+    return out, s[b : b + 4000]
+
+
+def loop_tree(path, kernel):
+    """parent header of every loop header (from the `Parent Loop` comments)"""
+    s = open(path).read()
+    a = s.index("\n" + kernel + ":")
+    b = s.index(".Lfunc_end", a)
+    parent, depth = {}, {}
+    for m in re.finditer(r"^\.L(BB\d+_\d+):((?:[^\n]*\n\s+;)*[^\n]*)", s[a:b], re.M):
+        text = m.group(0)
+        d = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", text)
+        if not d:
+            continue
+        h = m.group(1)
+        depth[h] = int(d.group(1))
+        ps = re.findall(r"Parent Loop (BB\d+_\d+) Depth=(\d+)", text)
+        parent[h] = max(ps, key=lambda p: int(p[1]))[0] if ps else None
+    return parent, depth
+
+
+def analyse(path=ASM, kernel=K_ADD33):
+    bl, tail = blocks(path, kernel)
+    parent, depth = loop_tree(path, kernel)
+    total = zero()
+    excl = {h: zero() for h in parent}
+    for b in bl:
+        for k in KEYS:
+            total[k] += b["c"][k]
+            if b["header"] in excl:
+                excl[b["header"]][k] += b["c"][k]
+    res = {"kernel": kernel, "total": total,
+           "loops": [{"header": h, "depth": depth[h], "parent": parent[h], **excl[h]} for h in sorted(parent, key=lambda h: (depth[h], h))]}
+    m = re.search(r"\.private_seg_size, (\d+)", tail)
+    res["scratch_bytes_own"] = int(m.group(1)) if m else None
+    m = re.search(r"\.num_vgpr, (?:max\()?(\d+)", tail)
+    res["vgpr"] = int(m.group(1)) if m else None
+    # the loop nest of k_add: launch loop (depth 1, with children) > table loop (depth 2, with children) > `which` loop
+    kids = {h: [c for c in parent if parent[c] == h] for h in parent}
+    launch = [h for h in parent if depth[h] == 1 and kids[h]]
+    if launch:
+        L = max(launch, key=lambda h: sum(excl[c]["valu"] for c in kids[h]))
+        table = [c for c in kids[L] if kids[c]]
+        prefix = [c for c in kids[L] if not kids[c]]
+        if table:
+            T = table[0]
+            W = max(kids[T], key=lambda h: excl[h]["valu"])
+            est = {k: float(excl[W][k]) + excl[T][k] / 2.0 for k in ("valu", "mad64", "fast", "other")}
+            if prefix:
+                P = max(prefix, key=lambda h: excl[h]["valu"])
+                for k in est:
+                    est[k] += excl[P][k] / 2.0
+                res["prefix_loop"] = excl[P]
+            res["which_loop"], res["table_loop"], res["launch_loop"] = excl[W], excl[T], excl[L]
+            res["per_key_static"] = est
+            res["fingerprint"] = {"kernel_valu": total["valu"], "which_loop_valu": excl[W]["valu"], "which_loop_mad64": excl[W]["mad64"],
+                                  "which_loop_fast": excl[W]["fast"], "table_loop_valu": excl[T]["valu"],
+                                  "prefix_loop_valu": res.get("prefix_loop", zero())["valu"], "scratch_instr": total["scratch"]}
+    return res
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0] if args else ASM
+    kernel = args[1] if len(args) > 1 else K_ADD33
+    a = analyse(path, kernel)
+    if "--json" in sys.argv:
+        print(json.dumps(a, indent=1))
+        return
+    t = a["total"]
+    print("%s: %d VALU (%d mad64, %d fast, %d other), %d SALU, %d VMEM, %d SMEM, %d LDS, %d scratch instr; %s VGPRs, %s B scratch (own)" %
+          (kernel, t["valu"], t["mad64"], t["fast"], t["other"], t["salu"], t["vmem"], t["smem"], t["lds"], t["scratch"],
+           a["vgpr"], a["scratch_bytes_own"]))
+    for l in a["loops"]:
+        print("  %sloop %-10s (in %s): VALU %5d  mad64 %4d  fast %4d  other %5d  vmem %d lds %d scratch %d" %
+              ("  " * (l["depth"] - 1), l["header"], l["parent"], l["valu"], l["mad64"], l["fast"], l["other"], l["vmem"], l["lds"], l["scratch"]))
+    if "per_key_static" in a:
+        print("per key (static, upper estimate): %s" % {k: round(v, 1) for k, v in a["per_key_static"].items()})
+        print("fingerprint: %s" % a["fingerprint"])
 
 
 if __name__ == "__main__":
-    kernel = sys.argv[2] if len(sys.argv) > 2 else "_Z5k_addILb1ELb0ELb0EEv8add_args"
-    for name, c in blocks(sys.argv[1], kernel):
-        n = sum(c.values())
-        if n >= 8:
-            cyc = sum(c[k] * COST[k] for k in c)
-            print("%-12s VALU %5d  mad64 %4d  fast %4d  other %5d  -> %7.0f cycles (%.2f / instr)" % (name, n, c["mad64"], c["fast"], c["other"], cyc, cyc / n))
+    main()
