@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count",
 ]
 
 _lib = None
@@ -58,6 +58,7 @@ def load():
     lib.ecl_hip_mul_batch.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_bloom_insert.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_get_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
+    lib.ecl_hip_bloom_insert_count.argtypes = [P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ecl_hip_set_geometry.argtypes = [P, C.c_uint32, C.c_uint32]
     lib.ecl_hip_get_geometry.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -136,6 +137,13 @@ class Device:
     def bloom_insert(self, hashes):
         H = np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)
         self._chk(self.lib.ecl_hip_bloom_insert(self.h, H.ctypes.data, len(H)))
+
+    def bloom_insert_count(self, hashes):
+        """blf-gen's insert loop (utils.c:455-470) on the device -> number of hashes that were new, in input order"""
+        H = np.ascontiguousarray(hashes, dtype=np.uint32).reshape(-1, 5)
+        added = C.c_uint64()
+        self._chk(self.lib.ecl_hip_bloom_insert_count(self.h, H.ctypes.data, len(H), C.byref(added)))
+        return added.value
 
     def get_bloom(self, nwords):
         w = np.zeros(nwords, dtype=np.uint64)

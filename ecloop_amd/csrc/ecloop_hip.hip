@@ -269,6 +269,79 @@ __global__ void k_bloom_insert(bloom_t b, u64* bits, const u32* h160, u64 n) {
   bloom_add(b, bits, h);
 }
 
+// ---- blf-gen's insert loop (utils.c:455-470) in bulk WITH its count: a hash is "new" iff at its turn (input order) at
+// least one of its 20 bits is still clear.  The bits themselves do not depend on the order (ORs commute); the count
+// does, so it is resolved per chunk of 2^20 hashes: every bit that is clear before the chunk and wanted by a hash of
+// the chunk gets an OWNER - the smallest index wanting it - in an open-addressing table (key = bit position, value =
+// index, one 64-bit word: atomicCAS claims a slot for a position, atomicMin keeps the smallest index); a hash is new
+// iff it owns at least one bit.  Exactly the sequential answer, duplicates and colliding hashes included.
+#define BLF_CHUNK_LOG2 20u
+#define BLF_TAB_LOG2 26u  /* 2^26 slots for <= 20 * 2^20 wanted bits: load <= 0.32 */
+#define BLF_EMPTY (~0ull)
+__device__ __forceinline__ u64 blf_slot_hash(u64 p) {
+  p *= 0x9E3779B97F4A7C15ull;
+  return p >> (64 - BLF_TAB_LOG2);
+}
+__device__ __forceinline__ u64 blf_bitpos(const bloom_t& b, u64 idx) { return bloom_mod(b, idx >> 6) * 64 + (idx & 63); }
+__global__ void k_blf_claim(bloom_t b, const u32* __restrict__ h160, u32 n, u64* __restrict__ tab) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 h[5];
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h[w] = h160[(size_t)i * 5 + w];
+  u64 a[5];
+  bloom_words_of(a, h);
+#pragma unroll
+  for (int p = 0; p < 20; ++p) {  // unrolled: a[] must stay in registers (no runtime indexing)
+    const u64 pos = blf_bitpos(b, bloom_index(a, p));
+    if ((b.bits[pos >> 6] >> (pos & 63)) & 1) continue;  // set before this chunk: nobody's
+    const u64 pack = pos << BLF_CHUNK_LOG2 | i;
+    u64 slot = blf_slot_hash(pos);
+    for (;;) {
+      u64 cur = tab[slot];
+      if (cur == BLF_EMPTY) {
+        cur = atomicCAS((unsigned long long*)&tab[slot], BLF_EMPTY, pack);
+        if (cur == BLF_EMPTY) break;
+      }
+      if ((cur >> BLF_CHUNK_LOG2) == pos) {
+        atomicMin((unsigned long long*)&tab[slot], pack);
+        break;
+      }
+      slot = (slot + 1) & ((1ull << BLF_TAB_LOG2) - 1);
+    }
+  }
+}
+__global__ void k_blf_count_and_set(bloom_t b, u64* __restrict__ bits, const u32* __restrict__ h160, u32 n, const u64* __restrict__ tab,
+                                    unsigned long long* __restrict__ added) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool is_new = false;
+  if (i < n) {
+    u32 h[5];
+#pragma unroll
+    for (int w = 0; w < 5; ++w) h[w] = h160[(size_t)i * 5 + w];
+    u64 a[5];
+    bloom_words_of(a, h);
+#pragma unroll
+    for (int p = 0; p < 20; ++p) {
+      const u64 pos = blf_bitpos(b, bloom_index(a, p));
+      u64 slot = blf_slot_hash(pos);
+      for (;;) {  // owner lookup: absent = the bit was set before the chunk
+        const u64 cur = tab[slot];
+        if (cur == BLF_EMPTY) break;
+        if ((cur >> BLF_CHUNK_LOG2) == pos) {
+          is_new |= (u32)(cur & ((1u << BLF_CHUNK_LOG2) - 1)) == i;
+          break;
+        }
+        slot = (slot + 1) & ((1ull << BLF_TAB_LOG2) - 1);
+      }
+    }
+  }
+  const u64 m = __builtin_amdgcn_ballot_w64(is_new);
+  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(added, (unsigned long long)__builtin_popcountll(m));
+  // the bits are set by a separate launch of k_bloom_insert AFTER this kernel: owners are looked up against the
+  // filter state before the chunk
+}
+
 // ------------------------------------------------------------------------------------------------ context
 
 struct ecl_hip {
@@ -986,6 +1059,40 @@ extern "C" int ecl_hip_bloom_insert(ecl_hip* h, const uint32_t (*h160)[5], uint6
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_bloom_insert_count(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n, uint64_t* added) {
+  if (!h || (!h160 && n) || !added) return ECL_E_ARG;
+  *added = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  if (h->bloom_words >= (1ull << (64 - BLF_CHUNK_LOG2 - 6))) return ECL_E_ARG;  // bit position must fit 44 bits (2 TB filter)
+  HIPCHK(h, hipSetDevice(h->dev));
+  const u64 chunk = 1ull << BLF_CHUNK_LOG2;
+  dbuf<u32> dh;
+  dbuf<u64> tab;
+  dbuf<unsigned long long> cnt;
+  HIPCHK(h, hipMalloc(&dh.p, (size_t)(n < chunk ? n : chunk) * 20));
+  HIPCHK(h, hipMalloc(&tab.p, sizeof(u64) << BLF_TAB_LOG2));
+  HIPCHK(h, hipMalloc(&cnt.p, sizeof(unsigned long long)));
+  HIPCHK(h, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), h->stream));
+  const bloom_t b = bloom_make(h->d_bloom, h->bloom_words);
+  for (u64 at = 0; at < n; at += chunk) {
+    const u32 m = (u32)(n - at < chunk ? n - at : chunk);
+    HIPCHK(h, hipMemcpyAsync(dh.p, h160 + at, (size_t)m * 20, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(tab.p, 0xFF, sizeof(u64) << BLF_TAB_LOG2, h->stream));
+    hipLaunchKernelGGL(k_blf_claim, dim3((m + 255) / 256), dim3(256), 0, h->stream, b, dh.p, m, tab.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_blf_count_and_set, dim3((m + 255) / 256), dim3(256), 0, h->stream, b, h->d_bloom, dh.p, m, tab.p, cnt.p);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_bloom_insert, dim3((m + 255) / 256), dim3(256), 0, h->stream, b, h->d_bloom, dh.p, (u64)m);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the host buffer slice is free again; next chunk sees these bits
+  }
+  unsigned long long c = 0;
+  HIPCHK(h, hipMemcpy(&c, cnt.p, sizeof c, hipMemcpyDeviceToHost));
+  *added = c;
   return ECL_OK;
 }
 

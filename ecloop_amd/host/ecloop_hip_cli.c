@@ -871,6 +871,8 @@ static void cmd_rnd(ctx_t *ctx) {
   printf("[RANDOM MODE] offs: %d ~ bits: %d\n\n", ctx->ord_offs, ctx->ord_size);
   ctx->ts_started = tsnow();
   sc a = ctx->range_s, b = ctx->range_e;
+  const char *mw = getenv("ECLOOP_HIP_RND_WINDOWS");
+  u64 max_windows = mw ? strtoull(mw, NULL, 10) : 0, windows = 0;
   for (;;) {
     u64 last_c = ctx->k_checked, last_f = ctx->k_found, t0 = tsnow();
     sc s = sc_rand_range(&a, &b, !ctx->has_seed), e = s; /* gen_random_range, main.c:580-591 */
@@ -886,6 +888,18 @@ static void cmd_rnd(ctx_t *ctx) {
     term_clear_line();
     printf("%'llu / %'llu ~ %.1fs\n\n", (unsigned long long)df, (unsigned long long)dc, dt);
     if (is_full) break;
+    /* the reference loops until interrupted; ECLOOP_HIP_RND_WINDOWS=N (tests, timing runs) stops after N windows */
+    if (max_windows && ++windows >= max_windows) break;
+  }
+  if (getenv("ECLOOP_HIP_STATS")) { /* where the device time of the windows went: search kernel vs per-window set-up */
+    for (int g = 0; g < ctx->ngpus; ++g) {
+      double kms = 0, sms = 0;
+      u64 launches = 0, keys = 0, setups = 0;
+      ecl_hip_get_timing(ctx->dev[g], &kms, &launches, &keys);
+      ecl_hip_get_setup_timing(ctx->dev[g], &sms, &setups);
+      printf("gpu %d: %llu launches, %.3f ms in the search kernel, %llu set-ups, %.3f ms in set-up kernels (%.2f %%)\n", g,
+             (unsigned long long)launches, kms, (unsigned long long)setups, sms, kms > 0 ? 100.0 * sms / (kms + sms) : 0.0);
+    }
   }
   ctx_finish(ctx);
 }
@@ -916,12 +930,42 @@ static void blf_gen(args_t *args) { /* utils.c:409-475 */
   printf("bloom filter params: n = %'llu | p = 1:%'llu | m = %'llu (%'.1f MB)\n", (unsigned long long)n, (unsigned long long)r, (unsigned long long)m, mb);
   u64 count = 0;
   char line[41];
-  while (fgets(line, sizeof line, stdin)) {
-    u32 h[5];
-    if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
-    if (blf_has(&blf, h)) continue;
-    blf_add(&blf, h), count++;
+  /* Filters sized for 2^16 entries and more are filled on the GPU when one is visible (`-host` keeps it here): the
+     same 20 bits per hash by atomic ORs, and the same "new items" count as this loop gives in input order
+     (ecl_hip_bloom_insert_count); the file written is byte-identical either way. */
+  ecl_hip *dev = NULL;
+  if (n >= (1u << 16) && !args_bool(args, "-host") && ecl_hip_device_count() > 0) {
+    int rc = ecl_hip_open(&dev, 0, ECL_ADDR33, 0);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(dev, blf.bits, blf.size);
+    if (rc != ECL_OK) { fprintf(stderr, "[!] GPU set-up failed: %s (%s)\n", ecl_hip_strerror(rc), dev ? ecl_hip_last_error(dev) : ""); exit(1); }
+    printf("inserting on GPU 0\n");
   }
+  if (dev) {
+    const size_t BATCH = 1u << 22;
+    u32 (*hs)[5] = malloc(BATCH * 20);
+    size_t have = 0;
+    bool more = true;
+    while (more) {
+      more = fgets(line, sizeof line, stdin) != NULL;
+      if (more && strlen(line) == 40 && parse_hash40(line, hs[have])) have++;
+      if (have == BATCH || (!more && have)) {
+        u64 added = 0;
+        int rc = ecl_hip_bloom_insert_count(dev, (const uint32_t(*)[5])hs, have, &added);
+        if (rc != ECL_OK) { fprintf(stderr, "[!] GPU insert failed: %s (%s)\n", ecl_hip_strerror(rc), ecl_hip_last_error(dev)); exit(1); }
+        count += added, have = 0;
+      }
+    }
+    int rc = ecl_hip_get_bloom(dev, blf.bits, blf.size);
+    if (rc != ECL_OK) { fprintf(stderr, "[!] reading the filter back failed: %s\n", ecl_hip_strerror(rc)); exit(1); }
+    ecl_hip_close(dev);
+    free(hs);
+  } else
+    while (fgets(line, sizeof line, stdin)) {
+      u32 h[5];
+      if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
+      if (blf_has(&blf, h)) continue;
+      blf_add(&blf, h), count++;
+    }
   printf("added %'llu new items; saving to %s\n", (unsigned long long)count, path);
   if (!blf_save(path, &blf)) { fprintf(stderr, "[!] failed to save bloom filter\n"); exit(1); }
 }

@@ -85,6 +85,10 @@ int ecl_hip_unpin_host(const void *p);
    filter; ecl_hip_get_bloom copies the bit array back (e.g. to write a .blf file, utils.c:328-360). */
 int ecl_hip_bloom_insert(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 int ecl_hip_get_bloom(ecl_hip *h, uint64_t *bits, uint64_t nwords);
+/* The insert loop of blf-gen (utils.c:455-470) for n hashes in input order: a hash that blf_has already reports at its
+   turn is skipped; *added = the number that were new - the reference's "added N new items", exact also for duplicate
+   and colliding hashes (the bits are those of ecl_hip_bloom_insert). */
+int ecl_hip_bloom_insert_count(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n, uint64_t *added);
 
 /* Optional exact confirm on the device: the second half of ctx_check_hash (main.c:212-216).  h160 = the n sorted,
    unique list entries (ctx->to_find_hashes, order of compare_160, addr.c:18-26).  With a list resident, add_range /

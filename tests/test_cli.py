@@ -164,6 +164,45 @@ def test_rnd_window_is_an_add_over_the_printed_bounds(cli, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size,mode,nwin", [(20, "ones", 1), (32, "a", 2)])
+def test_rnd_at_configs3_shape_equals_add_on_the_printed_masks(cli, tmp_path, size, mode, nwin):
+    """BASELINE configs[3]: `rnd -d 128:32` on a 168-bit range.  Every window the generator prints (two 64-digit masks,
+    main.c:593-617) must hash exactly the keys `add -r s:e -d 128:<size>` hashes on those bounds: the found sets are
+    compared window by window - all-ones filter (every key a hit) for 2^21-key windows, a half-dense synthetic filter
+    (~4096 false positives per 2^32 keys) for the full 2^32-key window of the named config."""
+    blf = str(tmp_path / "f.blf")
+    write_blf(blf, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(70001, seed=23, mode=mode))
+    lo, hi = (1 << 167) + 0x1234567, (1 << 168) - 0x7654321
+    out = str(tmp_path / "rnd.txt")
+    env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS=str(nwin), ECLOOP_HIP_STATS="1")
+    pr = subprocess.run([cli, "rnd", "-f", blf, "-r", f"{lo:x}:{hi:x}", "-d", f"128:{size}", "-seed", "graft", "-q", "-o", out],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert pr.returncode == 0, pr.stderr.decode()[-1000:]
+    text = pr.stdout.decode()
+    assert f"[RANDOM MODE] offs: 128 ~ bits: {size}" in text
+    masks = [int(l.replace(" ", ""), 16) for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
+    assert len(masks) == 2 * nwin
+    rnd_lines = sorted(l.rstrip("\n") for l in open(out))
+    want = []
+    for w in range(nwin):
+        s, e = masks[2 * w], masks[2 * w + 1]
+        field = ((1 << size) - 1) << 128
+        assert lo <= s < e <= hi
+        if s != lo and e != hi:  # not clipped to the range (main.c:586-589): bits offs..offs+size-1 cleared / set
+            assert s & field == 0 and e & field == field and s | field == e
+        lines, status, _ = run(cli, ["add", "-f", blf, "-r", f"{s:x}:{e:x}", "-d", f"128:{size}"], out=str(tmp_path / f"add{w}.txt"))
+        assert counts(status)[1] == max(1 << size, 1 << 21)
+        want += lines
+    assert rnd_lines == sorted(want)
+    assert len(rnd_lines) == (nwin << 21 if mode == "ones" else len(rnd_lines)) and len(rnd_lines) > 1000
+    # every key of a window differs from its start only in the window's bit field
+    for l in rnd_lines[:: max(1, len(rnd_lines) // 500)]:
+        k = int(l.split("\t")[2], 16)
+        assert any((k ^ masks[2 * w]) & ~(((1 << max(size, 21)) - 1) << 128) == 0 for w in range(nwin)), hex(k)
+    assert "set-ups" in text
+
+
+@pytest.mark.gpu
 def test_pause_resume_keys(cli, tmp_path):
     """'p' / 'r' (main.c:874-888, lib/utils.c:559-626): the scan stops at the next status update, the status line offers
     the other key, the counter stands still, and the paused time is not in the reported time.  The keys are fed through

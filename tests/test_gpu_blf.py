@@ -54,3 +54,56 @@ def test_bulk_insert_random_hashes_bit_for_bit(nwords):
     L.orc_blf_add_many.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.orc_blf_add_many(want.ctypes.data, nwords, h.ctypes.data, n)
     assert np.array_equal(got, want)
+
+
+def test_insert_count_is_the_sequential_count():
+    """ecl_hip_bloom_insert_count = blf-gen's loop (utils.c:455-470): `if (blf_has) continue; blf_add; count++` in input
+    order.  Inputs with exact duplicates (inside one 2^20-hash chunk and across chunks), with hashes already present,
+    and with a filter so small that distinct hashes collide on every bit: count and bits must equal the oracle's."""
+    from ecloop_amd import Device
+    L = orc.lib()
+    L.orc_blf_gen_many.restype = C.c_uint64
+    L.orc_blf_gen_many.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(77)
+    base = np.ascontiguousarray(splitmix64(3 * 1_500_000, 31).view(np.uint32).reshape(-1, 6)[:, :5])
+    cases = []
+    dup = np.concatenate([base[:600_000], base[:300_000], base[1_200_000:], base[100_000:200_000]])  # duplicates, 2 chunks
+    cases.append(((1 << 20) + 7, rng.permutation(dup)))
+    cases.append((64, base[:50_000]))         # 4096 bits: saturates, almost nothing is new after the first few hundred
+    cases.append((1, base[:1000]))            # 64 bits
+    cases.append((65539, np.repeat(base[:1000], 5, axis=0)))  # every hash five times in a row
+    for nwords, h in cases:
+        h = np.ascontiguousarray(h)
+        want_bits = np.zeros(nwords, np.uint64)
+        want_bits[: min(3, nwords)] = np.uint64(0x0123456789ABCDEF)  # a filter that is not empty to begin with
+        start = want_bits.copy()
+        want = L.orc_blf_gen_many(want_bits.ctypes.data, nwords, h.ctypes.data, len(h))
+        d = Device(0)
+        try:
+            d.set_bloom(start)
+            got = d.bloom_insert_count(h)
+            bits = d.get_bloom(nwords)
+            assert d.bloom_insert_count(h[:5000]) == 0  # everything is in now
+        finally:
+            d.close()
+        assert got == want and np.array_equal(bits, want_bits), (nwords, got, want)
+
+
+def test_cli_blf_gen_uses_the_device_above_65536_entries(tmp_path):
+    """`ecloop-hip blf-gen -n 100000` fills the filter on the GPU: file and "added N new items" equal the host path's"""
+    import subprocess
+    from ecloop_amd.build import build_host_cli, build_library
+    build_library()
+    cli = build_host_cli()
+    h = np.ascontiguousarray(splitmix64(3 * 90_000, 5).view(np.uint32).reshape(-1, 6)[:, :5])
+    h = np.concatenate([h, h[:1234]])
+    text = "".join("%08x%08x%08x%08x%08x\n" % tuple(int(v) for v in row) for row in h).encode()
+    outs = {}
+    for mode, extra in (("gpu", []), ("host", ["-host"])):
+        f = str(tmp_path / (mode + ".blf"))
+        pr = subprocess.run([cli, "blf-gen", "-n", "100000", "-o", f] + extra, input=text, stdout=subprocess.PIPE, check=True)
+        outs[mode] = (open(f, "rb").read(), pr.stdout.decode())
+    assert outs["gpu"][0] == outs["host"][0]
+    assert "inserting on GPU 0" in outs["gpu"][1] and "inserting on GPU" not in outs["host"][1]
+    added = lambda t: [l for l in t.splitlines() if l.startswith("added")][0]
+    assert added(outs["gpu"][1]) == added(outs["host"][1]) and "90" in added(outs["gpu"][1])

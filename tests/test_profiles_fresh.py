@@ -1,0 +1,50 @@
+"""The tracked PMC profile must belong to the kernel that is being built: bench.py prices its roofline with
+profiles/r<NN>_roofline.json (VALU instructions per key, HBM bytes, clock - measured on the GPU box for ONE build), so
+a change to the add kernel that is not followed by a new collection run has to fail here, not go unnoticed.
+The check is static: the instruction mix of k_add<addr33> in the assembly of the freshly built library
+(tools/isa_mix.py) against the fingerprint stored in the profile, 1 % tolerance per field."""
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def newest_profile():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_roofline.json")))
+    assert files, "no profiles/rNN_roofline.json: run tools/collect_profiles.sh on the GPU box"
+    return json.load(open(files[-1])), os.path.basename(files[-1])
+
+
+def test_static_mix_of_the_built_kernel_matches_the_profile():
+    from ecloop_amd.build import ASM, build_library
+    import isa_mix
+    build_library()  # no-op when current; always leaves the assembly of the shipped code object beside the library
+    assert os.path.exists(ASM)
+    a = isa_mix.analyse(ASM)
+    prof, name = newest_profile()
+    fp, want = a["fingerprint"], prof["fingerprint"]
+    for k, v in want.items():
+        assert abs(fp[k] - v) <= max(0.01 * v, 1), f"{k}: built {fp[k]} vs {v} in {name}: re-run tools/collect_profiles.sh"
+    # the loop nest the estimate relies on is the one add_kernel.h describes
+    assert a["which_loop"]["valu"] > 2500 and a["table_loop"]["mad64"] >= 162 and a["prefix_loop"]["mad64"] >= 81
+    # spill traffic stays out of the per-key loops: scratch instructions only in the once-per-group launch loop
+    assert a["which_loop"]["scratch"] == 0 and a["table_loop"]["scratch"] == 0 and a["prefix_loop"]["scratch"] == 0
+    est = a["per_key_static"]["valu"]
+    pmc = prof["derived"]["valu_lane_ops_per_key"]
+    assert 0.97 < est / pmc < 1.10, (est, pmc)  # static upper estimate vs the PMC count of the profiled build
+
+
+def test_profile_is_self_consistent():
+    prof, name = newest_profile()
+    d, t, c = prof["derived"], prof["traffic"], prof["corrections"]
+    assert 2500 < d["valu_lane_ops_per_key"] < 4000 and 1.8 < d["clock_ghz"] < 2.5 and 3.0 < d["simd_cycles_per_valu_instr"] < 5.0
+    # cycles per instruction = clock x time x SIMDs / instructions
+    cyc = d["clock_ghz"] * 1e9 * prof["profiled_launch_ms"] * 1e-3 * 1024 / prof["pmc"]["SQ_INSTS_VALU"]
+    assert abs(cyc - d["simd_cycles_per_valu_instr"]) < 1e-6
+    # streaming calibration: FETCH_SIZE reports half of a coalesced 16-byte-per-lane read, WRITE_SIZE all of a write
+    assert abs(c["fetch_stream16_reported_over_actual"] - 0.5) < 0.02 and abs(c["write_stream16_reported_over_actual"] - 1.0) < 0.02
+    assert 56 < c["fetch_reported_bytes_per_random8_rd_5900MB"] < 70  # one 64-byte request per random 8-byte probe
+    assert abs(t["bytes_per_key_corrected"] - (t["chain_bytes_per_key_each_way"] + t["probe_fetch_bytes_per_key_reported"] + t["write_bytes_per_key_corrected"])) < 1e-6
