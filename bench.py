@@ -243,11 +243,16 @@ def bench_mul(args, rank, world, local, dist, barrier):
     import torch
     from ecloop_amd.engine import Filter, KeySearch
     n = 1 << args.mul_log2
-    ks = KeySearch(Filter(np.zeros(64, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr, verify=False)
+    addr = args.addr if "--addr" in sys.argv else "cu"  # configs[4] / `make mul`: -a cu
+    args.addr = addr
+    ks = KeySearch(Filter(np.zeros(64, dtype=np.uint64)), device=local, a33="c" in addr, a65="u" in addr, verify=False)
     rng = np.random.default_rng(1234 + rank)
     scal = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
     lib, h = ks.dev.lib, ks.dev.h
     import ctypes as C
+    if not args.pageable:  # the C host program keeps its scalar arrays in page-locked memory too (ecl_hip_alloc_host)
+        if lib.ecl_hip_pin_host(scal.ctypes.data, scal.nbytes) != 0:
+            raise SystemExit("[bench] cannot pin the scalar array")
     out = np.zeros(64, dtype=np.dtype([("b", "u1", (32,))]))
     cnt = C.c_uint32()
 
@@ -278,7 +283,8 @@ def bench_mul(args, rank, world, local, dist, barrier):
            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": {"workload": f"mul -a {args.addr}: 2^{args.mul_log2} seeded 256-bit scalars per GPU per step from HOST memory through "
-                                  "ecl_hip_mul_batch (copies overlapped with the kernel), empty filter", "hashes_per_scalar": hashes},
+                                  "ecl_hip_mul_batch (copies overlapped with the kernel), empty filter", "hashes_per_scalar": hashes,
+                      "host_memory": "pageable (staged)" if args.pageable else "page-locked (direct DMA)"},
            "roofline": {"bound": "valu-int32", "kernel": "k_mul_check", "ms_per_call_on_stream": round(ms / max(calls, 1), 3),
                         "device_mscalars_s": round(nsc / (ms * 1e-3) / 1e6, 2) if ms else None,
                         "pcie_gbs": round(nsc * 32 / (ms * 1e-3) / 1e9, 2) if ms else None}}
@@ -311,6 +317,7 @@ def main():
     ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
     ap.add_argument("--cmd", default="add", choices=["add", "mul"], help="mul: the non-headline `mul` path")
     ap.add_argument("--mul-log2", type=int, default=24)
+    ap.add_argument("--pageable", action="store_true", help="mul: scalars in pageable host memory (staged through pinned buffers by the library)")
     args = ap.parse_args()
     t_process = time.perf_counter()
 

@@ -38,8 +38,23 @@ __global__ void random8_rd(const uint64_t* __restrict__ p, uint64_t nwords, uint
   if (acc == 0x12345678u) out[0] = (uint32_t)acc;
 }
 
+static hipEvent_t e0, e1;
+#define TIMED(name, units, call)                                                           \
+  do {                                                                                     \
+    CHECK(hipEventRecord(e0));                                                             \
+    call;                                                                                  \
+    CHECK(hipEventRecord(e1));                                                             \
+    CHECK(hipEventSynchronize(e1));                                                        \
+    float ms_;                                                                             \
+    CHECK(hipEventElapsedTime(&ms_, e0, e1));                                              \
+    printf("TIME %s %.3f ms  %.2f G requests/s  %.1f GB/s algorithmic\n", name, ms_, (units) / ms_ / 1e6, (units) * bytes_per_ / ms_ / 1e6); \
+  } while (0)
+
 int main() {
   CHECK(hipSetDevice(0));
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  double bytes_per_ = 16;
   uint32_t* out;
   CHECK(hipMalloc(&out, 64));
   const size_t big = (size_t)5900 << 20, small = (size_t)54 << 20;  // bytes
@@ -48,24 +63,21 @@ int main() {
   CHECK(hipMemset(a, 0x5a, big));
   CHECK(hipDeviceSynchronize());
   // streaming read / write of the whole 5.9 GB array (far beyond the 256 MB Infinity Cache)
-  hipLaunchKernelGGL(stream16_rd, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)a, big / 16, out);
-  CHECK(hipDeviceSynchronize());
+  TIMED("stream16_rd", (double)(big / 16), hipLaunchKernelGGL(stream16_rd, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)a, big / 16, out));
   printf("CALIB stream16_rd %zu %zu\n", big / 16, big);
-  hipLaunchKernelGGL(stream16_wr, dim3(256 * 32), dim3(256), 0, 0, (uint4*)a, big / 16, 3u);
-  CHECK(hipDeviceSynchronize());
+  TIMED("stream16_wr", (double)(big / 16), hipLaunchKernelGGL(stream16_wr, dim3(256 * 32), dim3(256), 0, 0, (uint4*)a, big / 16, 3u));
   printf("CALIB stream16_wr %zu %zu\n", big / 16, big);
   // random 8-byte probes: 2^28 of them, over 54 MB and over 5.9 GB.  Two launches each (the first warms the caches
   // for the small array; both are reported, the profile summary lists them in launch order)
   const uint32_t per = 16;
   const uint64_t lanes = 1ull << 24;
+  bytes_per_ = 8;
   for (int rep = 0; rep < 2; ++rep) {
-    hipLaunchKernelGGL(random8_rd, dim3((unsigned)(lanes / 256)), dim3(256), 0, 0, a, (uint64_t)(small / 8), per, out);
-    CHECK(hipDeviceSynchronize());
+    TIMED("random8_rd_54MB", (double)(lanes * per), hipLaunchKernelGGL(random8_rd, dim3((unsigned)(lanes / 256)), dim3(256), 0, 0, a, (uint64_t)(small / 8), per, out));
     printf("CALIB random8_rd_54MB %llu %llu\n", (unsigned long long)(lanes * per), (unsigned long long)(lanes * per * 8));
   }
   for (int rep = 0; rep < 2; ++rep) {
-    hipLaunchKernelGGL(random8_rd, dim3((unsigned)(lanes / 256)), dim3(256), 0, 0, a, (uint64_t)(big / 8), per, out);
-    CHECK(hipDeviceSynchronize());
+    TIMED("random8_rd_5900MB", (double)(lanes * per), hipLaunchKernelGGL(random8_rd, dim3((unsigned)(lanes / 256)), dim3(256), 0, 0, a, (uint64_t)(big / 8), per, out));
     printf("CALIB random8_rd_5900MB %llu %llu\n", (unsigned long long)(lanes * per), (unsigned long long)(lanes * per * 8));
   }
   CHECK(hipFree(a));

@@ -111,6 +111,12 @@ K32_2D(k_add_f32_e32, "v_add_f32_e32")
 K32_2D(k_add_u32_d, "v_add_u32_e32")
 K32_2D(k_or_b32_d, "v_or_b32_e32")
 K32_2D(k_lshrrev_b32_d, "v_lshrrev_b32_e32")
+K32_2D(k_lshlrev_b32_d, "v_lshlrev_b32_e32")
+K32_2(k_lshrrev_b32_s, "v_lshrrev_b32")
+K32_2D(k_mul_u32_u24_d, "v_mul_u32_u24_e32")
+K32_2D(k_mul_lo_u32_d, "v_mul_lo_u32")
+K32_2D(k_ashrrev_d, "v_ashrrev_i32_e32")
+K32_2D(k_max_u32_d, "v_max_u32_e32")
 K32_2D(k_min_u32_d, "v_min_u32_e32")
 K32_2D(k_cndmask_d, "v_cndmask_b32_e32")
 K32_2D(k_mul_lo_u16_d, "v_mul_lo_u16_e32")
@@ -380,7 +386,9 @@ int main(int argc, char** argv) {
       {"v_add_f32_e32   (distinct regs)", k_add_f32_e32, 32}, {"v_fma_f32 VOP3  (distinct regs)", k_fma_f32_d, 32},
       {"v_add_u32_e32   (distinct regs)", k_add_u32_d, 32}, {"v_or_b32_e32    (distinct regs)", k_or_b32_d, 32},
       {"v_mov_b32_e32", k_mov_b32, 32}, {"v_not_b32_e32", k_not_b32, 32}, {"v_bfrev_b32_e32", k_bfrev_b32, 32},
-      {"v_cndmask_b32_e32 (vcc)", k_cndmask_d, 32}, {"v_min_u32_e32", k_min_u32_d, 32}, {"v_lshrrev_b32_e32 (distinct regs)", k_lshrrev_b32_d, 32},
+      {"v_cndmask_b32_e32 (vcc)", k_cndmask_d, 32}, {"v_min_u32_e32", k_min_u32_d, 32}, {"v_lshrrev_b32_e32 (distinct regs)", k_lshrrev_b32_d, 32}, {"v_lshlrev_b32_e32 (distinct regs)", k_lshlrev_b32_d, 32},
+      {"v_lshrrev_b32 (shared operand)", k_lshrrev_b32_s, 32}, {"v_ashrrev_i32_e32 (distinct regs)", k_ashrrev_d, 32},
+      {"v_mul_u32_u24_e32 (distinct regs)", k_mul_u32_u24_d, 32}, {"v_mul_lo_u32 (distinct regs)", k_mul_lo_u32_d, 32}, {"v_max_u32_e32", k_max_u32_d, 32},
       {"v_mul_lo_u16_e32", k_mul_lo_u16_d, 32}, {"v_pk_mul_lo_u16", k_pk_mul_lo_u16_d, 32},
       {"v_bitop3_b32    (distinct regs)", k_bitop3_d, 32}, {"v_alignbit_b32  (distinct regs)", k_alignbit_d, 32},
       {"v_add3_u32      (distinct regs)", k_add3_d, 32}, {"v_bfe_u32", k_bfe_u32_d, 32}, {"v_xad_u32", k_xad_u32_d, 32},

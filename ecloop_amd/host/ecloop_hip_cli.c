@@ -23,7 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/select.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <termios.h>
 #include <unistd.h>
@@ -668,7 +670,7 @@ static void *pack_worker(void *arg) {
 /* text chunks: reader thread -> parser */
 #define MUL_TEXT_CHUNK ((size_t)64 << 20)
 #define MUL_TEXT_RING 3
-typedef struct { char *buf; size_t len; } text_chunk;
+typedef struct { char *buf, *own; size_t len; } text_chunk; /* buf = own (a ring buffer) or a slice of the mapped input */
 typedef struct {
   text_chunk ring[MUL_TEXT_RING];
   int head, tail, count; /* filled chunks: [tail, head) */
@@ -678,6 +680,40 @@ typedef struct {
 } text_queue;
 static void *mul_reader(void *arg) {
   text_queue *q = arg;
+  /* a regular file on stdin is mapped: the parse threads read (and page in) their slices in parallel, nothing is copied */
+  struct stat stt;
+  off_t pos = lseek(0, 0, SEEK_CUR);
+  if (pos >= 0 && fstat(0, &stt) == 0 && S_ISREG(stt.st_mode) && stt.st_size > pos) {
+    size_t size = (size_t)stt.st_size;
+    char *map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, 0, 0);
+    if (map != MAP_FAILED) {
+      madvise(map, size, MADV_SEQUENTIAL);
+      for (size_t at = (size_t)pos; at < size;) {
+        size_t end = at + MUL_TEXT_CHUNK < size ? at + MUL_TEXT_CHUNK : size;
+        if (end < size) {
+          if (q->bin) end = at + (end - at) / 32 * 32;
+          else {
+            size_t e = end;
+            while (e > at && map[e - 1] != '\n') e--;
+            if (e > at) end = e;
+          }
+        }
+        pthread_mutex_lock(&q->mu);
+        while (q->count == MUL_TEXT_RING) pthread_cond_wait(&q->cv, &q->mu);
+        text_chunk *c = &q->ring[q->head];
+        c->buf = map + at, c->len = end - at;
+        q->head = (q->head + 1) % MUL_TEXT_RING, q->count++;
+        pthread_cond_broadcast(&q->cv);
+        pthread_mutex_unlock(&q->mu);
+        at = end;
+      }
+      pthread_mutex_lock(&q->mu);
+      q->eof = true;
+      pthread_cond_broadcast(&q->cv);
+      pthread_mutex_unlock(&q->mu);
+      return NULL; /* the mapping stays until exit: the last chunks are still being parsed */
+    }
+  }
   char *carry = malloc(MUL_TEXT_CHUNK);
   size_t have = 0;
   for (;;) {
@@ -685,6 +721,7 @@ static void *mul_reader(void *arg) {
     while (q->count == MUL_TEXT_RING) pthread_cond_wait(&q->cv, &q->mu);
     text_chunk *c = &q->ring[q->head];
     pthread_mutex_unlock(&q->mu);
+    c->buf = c->own;
     memcpy(c->buf, carry, have);
     size_t got;
     while (have < MUL_TEXT_CHUNK && (got = fread(c->buf + have, 1, MUL_TEXT_CHUNK - have, stdin)) > 0) have += got;
@@ -711,7 +748,22 @@ static void *mul_reader(void *arg) {
 }
 /* parsed arrays: parser -> device threads */
 #define MUL_MAX_ARRAYS (MAX_GPUS + 2)
-typedef struct { u64 (*ks)[4]; size_t cap, n; } scalar_array;
+typedef struct { u64 (*ks)[4]; size_t cap, n; bool pinned; } scalar_array;
+/* scalar arrays live in page-locked memory so that the GPUs read them by DMA (no staging copy in ecl_hip_mul_batch) */
+static void ks_free(const ctx_t *ctx, u64 (*ks)[4], bool pinned) {
+  (void)ctx;
+  if (pinned) ecl_hip_free_host(ks);
+  else free(ks);
+}
+static void ks_grow(const ctx_t *ctx, scalar_array *ar, size_t n) {
+  if (n <= ar->cap) return;
+  ks_free(ctx, ar->ks, ar->pinned);
+  size_t cap = n + n / 8 + 1024;
+  ar->ks = ctx->parse_only ? NULL : ecl_hip_alloc_host(cap * 32);
+  ar->pinned = ar->ks != NULL;
+  if (!ar->ks) ar->ks = malloc(cap * 32);
+  ar->cap = cap;
+}
 typedef struct {
   ctx_t *ctx;
   scalar_array arr[MUL_MAX_ARRAYS];
@@ -760,7 +812,7 @@ static void cmd_mul(ctx_t *ctx) {
   memset(&tq, 0, sizeof tq);
   tq.bin = ctx->bin_input;
   pthread_mutex_init(&tq.mu, NULL), pthread_cond_init(&tq.cv, NULL);
-  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].buf = malloc(MUL_TEXT_CHUNK);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = malloc(MUL_TEXT_CHUNK);
   scalar_queue sq;
   memset(&sq, 0, sizeof sq);
   sq.ctx = ctx, sq.narr = ctx->ngpus + 2;
@@ -786,7 +838,7 @@ static void cmd_mul(ctx_t *ctx) {
     scalar_array *ar = &sq.arr[ai];
     if (ctx->bin_input) {
       ar->n = c->len / 32;
-      if (ar->n > ar->cap) free(ar->ks), ar->ks = malloc(ar->n * 32), ar->cap = ar->n;
+      ks_grow(ctx, ar, ar->n);
       memcpy(ar->ks, c->buf, ar->n * 32);
     } else {
       pthread_t th[32];
@@ -802,7 +854,7 @@ static void cmd_mul(ctx_t *ctx) {
       for (int i = 0; i < ns; ++i) pthread_create(&th[i], NULL, parse_worker, &sl[i]);
       size_t total = 0;
       for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL), total += sl[i].count;
-      if (total > ar->cap) free(ar->ks), ar->ks = malloc(total * 32), ar->cap = total;
+      ks_grow(ctx, ar, total);
       ar->n = total;
       size_t off = 0;
       for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count, pthread_create(&th[i], NULL, pack_worker, &sl[i]);
@@ -823,8 +875,8 @@ static void cmd_mul(ctx_t *ctx) {
   pthread_mutex_unlock(&sq.mu);
   pthread_join(reader, NULL);
   for (int g = 0; g < ctx->ngpus; ++g) pthread_join(devth[g], NULL);
-  for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].buf);
-  for (int i = 0; i < sq.narr; ++i) free(sq.arr[i].ks);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
+  for (int i = 0; i < sq.narr; ++i) ks_free(ctx, sq.arr[i].ks, sq.arr[i].pinned);
   for (int i = 0; i < 32; ++i) free(sl[i].tmp);
   if (!ctx->parse_only) ctx_finish(ctx);
 }

@@ -80,6 +80,10 @@ int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
    hipHostRegister / hipHostUnregister so that a plain-C host needs no HIP headers. */
 int ecl_hip_pin_host(const void *p, size_t bytes);
 int ecl_hip_unpin_host(const void *p);
+/* ... or get page-locked host memory to begin with (hipHostMalloc / hipHostFree): scalar arrays given to
+   ecl_hip_mul_batch from such memory are read by the GPU's copy engine directly, without the staging copy. */
+void *ecl_hip_alloc_host(size_t bytes);
+void ecl_hip_free_host(void *p);
 
 /* blf_add (utils.c:290-306) in bulk: set the 20 bits of each of n hash160 values (h160_t words) in the resident
    filter; ecl_hip_get_bloom copies the bit array back (e.g. to write a .blf file, utils.c:328-360). */

@@ -61,7 +61,7 @@ done
 for set in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/cal_$set" -o c -- "$R/$T/fetch_calib" > "$O/cal_$set.log" 2>&1
   echo "# --pmc $set" >> "$O/calib.txt"
-  grep '^CALIB' "$O/cal_$set.log" >> "$O/calib.txt"
+  grep -E '^(CALIB|TIME)' "$O/cal_$set.log" >> "$O/calib.txt"
   python - "$O/cal_$set" >> "$O/calib.txt" <<'PY'
 import csv, glob, os, sys
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):

@@ -43,6 +43,9 @@ def main():
     import atexit, shutil
     atexit.register(shutil.rmtree, tmp, ignore_errors=True)
     blf = os.path.join(tmp, "bench.blf")
+    if a.filter_n > 50_000_000:  # the big filter is generated with torch on the GPU: torch's HIP runtime has to come up first
+        import torch
+        torch.cuda.init()
     d = Device(0)
     size, offs, _ = bench.build_filter(d, bench.RANGE_A, 1 << 32, a.filter_n)
     blf_save(blf, d.get_bloom(size))
