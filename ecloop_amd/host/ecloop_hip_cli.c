@@ -1215,14 +1215,24 @@ static int run_bench(args_t *args) {
   return 0;
 }
 
-typedef struct { ctx_t *ctx; int g, device; u32 flags; u64 share; int rc; } open_job;
+typedef struct { ctx_t *ctx; int g, device; u32 flags; u64 share; int rc; u64 t[5]; } open_job;
+static u64 usnow(void) {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return (u64)tv.tv_sec * 1000000 + tv.tv_usec;
+}
 static void *open_worker(void *arg) {
   open_job *j = arg;
   ctx_t *ctx = j->ctx;
+  j->t[0] = usnow();
   int rc = ecl_hip_open(&ctx->dev[j->g], j->device, j->flags, ctx->cmd == CMD_MUL ? 0 : ctx->ord_offs);
+  j->t[1] = usnow();
   if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx->dev[j->g], ctx->blf.bits, ctx->blf.size);
+  j->t[2] = usnow();
   if (rc == ECL_OK && ctx->list) rc = ecl_hip_set_list(ctx->dev[j->g], (const uint32_t(*)[5])ctx->list, ctx->list_count);
+  j->t[3] = usnow();
   if (rc == ECL_OK && j->share) rc = ecl_hip_reserve(ctx->dev[j->g], j->share, 4096);
+  j->t[4] = usnow();
   j->rc = rc;
   return NULL;
 }
@@ -1312,6 +1322,11 @@ int main(int argc, const char **argv) {
     for (int g = 0; g < ctx.ngpus; ++g) pthread_join(th[g], NULL);
     for (int g = 0; g < ctx.ngpus; ++g)
       if (jobs[g].rc != ECL_OK) die_ecl(&ctx, g, jobs[g].rc, "open");
+    if (getenv("ECLOOP_HIP_STATS"))
+      for (int g = 0; g < ctx.ngpus; ++g)
+        printf("gpu %d bring-up: open %.1f ms, filter upload %.1f ms, list %.1f ms, reserve(%llu keys) %.1f ms\n", g,
+               (jobs[g].t[1] - jobs[g].t[0]) / 1e3, (jobs[g].t[2] - jobs[g].t[1]) / 1e3, (jobs[g].t[3] - jobs[g].t[2]) / 1e3,
+               (unsigned long long)share, (jobs[g].t[4] - jobs[g].t[3]) / 1e3);
   }
   if (pinned) ecl_hip_unpin_host(ctx.blf.bits);
   double setup_s = (tsnow() - t_setup0) / 1000.0;

@@ -72,8 +72,38 @@ PY
   rm -rf "$O/cal_$set"
 done
 
+# the `mul` kernel: VALU instructions per scalar (bench.py --cmd mul prices its roofline with it)
+: > "$O/pmc_mul.txt"
+for set in "SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "VALUBusy"; do
+  ECL_HIP_SKIP_SELFTEST=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmcm" -o p -- python "$R/bench.py" --cmd mul --steps 1 --warmup 1 > "$O/pmcm.log" 2>&1
+  echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 2 x 2^24 scalars, -a cu)" >> "$O/pmc_mul.txt"
+  summ "$O/pmcm" k_mul_check >> "$O/pmc_mul.txt"
+  rm -rf "$O/pmcm"
+done
+
 cd "$R"
 python tools/make_roofline_profile.py "$O" "$TAG" > "$O/${TAG}_roofline.json" 2> "$O/make_profile.err"
+python - "$O/pmc_mul.txt" "$TAG" > "$O/${TAG}_mul.json" <<'PY'
+import json, sys
+pmc, ns = {}, []
+for line in open(sys.argv[1]):
+    f = line.split()
+    if f and f[0] == "PMC": pmc[f[2]] = (float(f[3]), int(f[4]))
+    if f and f[0] == "TRACE": ns.append(int(f[2]))
+scalars = 2 * (1 << 24)  # warm-up + one step
+out = {"tag": sys.argv[2], "kernel": "k_mul_check<addr33,addr65>", "workload": "bench.py --cmd mul: 2^24 scalars per step, -a cu, R = 16 scalars per thread",
+       "pmc": {k: v[0] for k, v in pmc.items()}, "dispatches": {k: v[1] for k, v in pmc.items()}, "derived": {}}
+if "SQ_INSTS_VALU" in pmc:
+    out["derived"]["valu_lane_ops_per_scalar"] = pmc["SQ_INSTS_VALU"][0] * 64 / scalars
+if "FETCH_SIZE" in pmc:
+    out["derived"]["fetch_bytes_per_scalar_reported"] = pmc["FETCH_SIZE"][0] * 1024 / scalars
+if "VALUBusy" in pmc:
+    out["derived"]["valu_busy_pct"] = pmc["VALUBusy"][0] / max(pmc["VALUBusy"][1], 1)
+if ns:
+    out["derived"]["kernel_ms_per_2^22_scalars"] = sum(ns) / len(ns) / 1e6
+print(json.dumps(out, indent=1))
+PY
+cp "$O/${TAG}_mul.json" "profiles/${TAG}_mul.json"
 # the final bench line, priced with the profile just taken
 cp "$O/${TAG}_roofline.json" "profiles/${TAG}_roofline.json"
 python bench.py > "$O/bench.json" 2> "$O/bench.err"
