@@ -207,6 +207,30 @@ __global__ void __launch_bounds__(64) k_mul_window_one(scalar_arg s, const u32* 
   for (int w = 0; w < 8; ++w) out[w] = xw[w], out[8 + w] = yw[w];
 }
 
+// pk_verify_hash (main.c:248-263) for the hits of a call: re-derive each reported private key's public key on a path
+// that shares nothing with the walk (fixed-base window sum over the table that the double-and-add kernel built, own
+// inversion per key) and hash it both ways.  One lane per key; ~0.15 ms whatever the count (the walk's hits are few).
+__global__ void __launch_bounds__(64) k_verify(const u32* __restrict__ k, u32 n, const u32* __restrict__ gtab, u32* __restrict__ h33,
+                                               u32* __restrict__ h65, u8* __restrict__ ok) {
+  const u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  u32 kk[9];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
+  kk[8] = 0;
+  fe x, y;
+  const int fin = jac_to_affine(x, y, gtable_mul(kk, gtab));
+  u32 xw[8], yw[8], h[5];
+  fe_to_words(xw, x), fe_to_words(yw, y);
+  hash160_33(h, xw, yw[0] & 1u);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h33[(size_t)i * 5 + w] = h[w];
+  hash160_65(h, xw, yw);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h65[(size_t)i * 5 + w] = h[w];
+  ok[i] = (u8)fin;
+}
+
 // ------------------------------------------------------------------------------------------------ diagnostics
 __global__ void k_diag_fe(int op, const u32* a, const u32* b, u32* r, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,6 +387,7 @@ struct ecl_hip {
   // `mul`: scalars travel in chunks through two pinned staging buffers, copy engine and kernel overlapped
   u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr}; u32 kbuf_cap = 0, pin_cap = 0;
   u32* d_multmp = nullptr;                     // parked Jacobian sums of one chunk (144 bytes per scalar)
+  void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
@@ -464,7 +489,7 @@ void ecl_hip_close(ecl_hip* h) {
     if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-  (void)hipFree(h->d_multmp);
+  (void)hipFree(h->d_multmp), (void)hipFree(h->d_ver);
   if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
   if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -988,6 +1013,35 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
   }
   return rc;
+}
+
+extern "C" int ecl_hip_verify(ecl_hip* h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h33)[5], uint32_t (*h65)[5], uint8_t* ok) {
+  if (!h || !k || !h33 || !h65 || !ok || n == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
+  if (n > h->ver_cap) {  // grow-only device staging: scalars 32 B, two hashes 20 B each, flag
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_ver) HIPCHK(h, hipFree(h->d_ver));
+    h->d_ver = nullptr, h->ver_cap = 0;
+    u32 cap = 256;
+    while (cap < n) cap <<= 1;
+    HIPCHK(h, hipMalloc(&h->d_ver, (size_t)cap * 76));
+    h->ver_cap = cap;
+  }
+  u8* base = (u8*)h->d_ver;
+  u32* dk = (u32*)base;
+  u32* d33 = (u32*)(base + (size_t)h->ver_cap * 32);
+  u32* d65 = (u32*)(base + (size_t)h->ver_cap * 52);
+  u8* dok = base + (size_t)h->ver_cap * 72;
+  HIPCHK(h, hipMemcpyAsync(dk, k, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_verify, dim3((n + 63) / 64), dim3(64), 0, h->stream, dk, n, h->d_gtab, d33, d65, dok);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h33, d33, (size_t)n * 20, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h65, d65, (size_t)n * 20, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ECL_OK;
 }
 
 extern "C" int ecl_hip_get_mul_timing(ecl_hip* h, double* ms, uint64_t* calls, uint64_t* scalars) {

@@ -253,12 +253,11 @@ class KeySearch:
     def close(self):
         self.dev.close()
 
-    # pk_verify_hash (main.c:248-263): re-derive the hit from its scalar with the independent double-and-add kernel
+    # pk_verify_hash (main.c:248-263): re-derive the hit from its scalar on a path that shares no kernel with the walk
     def _verify(self, recs):
         if not recs:
             return
-        xs, ys, ok = self.dev.diag_mulg([r.pk for r in recs])
-        h33, h65 = self.dev.diag_hash160(xs, ys)
+        h33, h65, ok = self.dev.verify([r.pk for r in recs])
         for i, r in enumerate(recs):
             h = h33[i] if r.label == "addr33" else h65[i]
             if not ok[i] or [int(v) for v in h] != [int(v) for v in r.h160]:

@@ -336,16 +336,15 @@ static void ctx_write_found(ctx_t *ctx, const char *label, const u32 h[5], sc pk
 static bool list_confirm(const ctx_t *ctx, const u32 h[5]) {
   return !ctx->list || bsearch(h, ctx->list, ctx->list_count, 20, cmp160) != NULL;
 }
-/* pk_verify_hash (main.c:248-263) for all hits of one device call: re-derive them from their scalars on the device
-   with the independent double-and-add kernel, in one batch (a round trip per hit costs 0.3 ms) */
+/* pk_verify_hash (main.c:248-263) for all hits of one device call: re-derive them from their scalars on the device in
+   one batch, on a path that shares no kernel with the walk (ecl_hip_verify: window-table sum, own inversion per key) */
 static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *hits, u32 n) {
   if (!n) return;
-  u64 (*k)[4] = malloc((size_t)n * 32), (*x)[4] = malloc((size_t)n * 32), (*y)[4] = malloc((size_t)n * 32);
+  u64 (*k)[4] = malloc((size_t)n * 32);
   u32 (*h33)[5] = malloc((size_t)n * 20), (*h65)[5] = malloc((size_t)n * 20);
   u8 *ok = malloc(n);
   for (u32 i = 0; i < n; ++i) memcpy(k[i], pks[i].w, 32);
-  int rc = ecl_hip_diag_mulg(ctx->dev[g], k, x, y, ok, n);
-  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(ctx->dev[g], x, y, h33, h65, n);
+  int rc = ecl_hip_verify(ctx->dev[g], k, n, h33, h65, ok);
   if (rc != ECL_OK) die_ecl(ctx, g, rc, "verify");
   for (u32 i = 0; i < n; ++i) {
     const u32 *r = hits[i].compressed ? h33[i] : h65[i], *h = hits[i].h160;
@@ -357,7 +356,7 @@ static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *
     fprintf(stderr, "rh: %08x%08x%08x%08x%08x\n", r[0], r[1], r[2], r[3], r[4]);
     exit(1);
   }
-  free(k), free(x), free(y), free(h33), free(h65), free(ok);
+  free(k), free(h33), free(h65), free(ok);
 }
 
 /* ------------------------------------------------------------------------------------------- add */

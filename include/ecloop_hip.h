@@ -120,6 +120,11 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
 
+/* pk_verify_hash (main.c:248-263) for n reported private keys in one go: both hash160 values of k*G, derived on the
+   device by a path that shares no kernel with the walk (fixed-base window sum + own inversion per key); ok[i] = 0
+   for k = 0 (mod n).  The caller compares with the hit's h160 and treats a mismatch as fatal, like the reference. */
+int ecl_hip_verify(ecl_hip *h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h33)[5], uint32_t (*h65)[5], uint8_t *ok);
+
 /* Geometry of the walk: half_group = table points per group (the reference fixes 1024: GROUP_INV_SIZE/2,
    main.c:17), max_lanes = keys walked concurrently.  0 keeps the default (1024 and 2^21 lanes; the walk parks
    lanes * half_group * 36 bytes of prefix products in HBM - 77 GB at the default - and takes fewer lanes by itself

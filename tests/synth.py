@@ -17,7 +17,7 @@ def splitmix64(n, seed):
 
 
 def synth_bloom_words(nwords, seed, mode):
-    """Random bloom bit array with a chosen bit density: 'a|(b&c)' -> 0.625, 'a|b' -> 0.75, 'a' -> 0.5."""
+    """Random bloom bit array with a chosen bit density: 'a|(b&c)' -> 0.625, 'a|b' -> 0.75, 'a' -> 0.5, 'a&(b|c)' -> 0.375."""
     a = splitmix64(nwords, seed * 3 + 1)
     b = splitmix64(nwords, seed * 3 + 2)
     c = splitmix64(nwords, seed * 3 + 3)
@@ -27,6 +27,8 @@ def synth_bloom_words(nwords, seed, mode):
         return a | b
     if mode == "a":
         return a
+    if mode == "a&(b|c)":  # 0.375: the bit density of a .blf at its design load (20 probes, 43 bits per entry)
+        return a & (b | c)
     raise ValueError(mode)
 
 

@@ -82,6 +82,11 @@ class FakeDevice:
         pts = [orc.point_of(k) for k in ks]
         return [p[0] for p in pts], [p[1] for p in pts], np.ones(len(ks), dtype=np.uint8)
 
+    def verify(self, ks):
+        xs, ys, ok = self.diag_mulg(ks)
+        h33, h65 = self.diag_hash160(xs, ys)
+        return h33, h65, ok
+
     def diag_hash160(self, xs, ys):
         return (np.array([orc.hash160(x, y, True) for x, y in zip(xs, ys)], dtype=np.uint32).reshape(-1, 5),
                 np.array([orc.hash160(x, y, False) for x, y in zip(xs, ys)], dtype=np.uint32).reshape(-1, 5))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # `rnd` window loop on one GPU (BASELINE configs[3] shape): N random windows of 2^SIZE keys at stride 2^128 over a
-# 168-bit range, sparse synthetic filter.  Prints the host program's per-window lines and, at the end, how the device
+# 168-bit range, synthetic 56 MB filter at the .blf design density.  Prints the host program's per-window lines and, at the end, how the device
 # time splits between the search kernel and the per-window set-up (ECLOOP_HIP_STATS).
 #   bash tools/bench_rnd.sh [SIZE=29] [WINDOWS=40]
 SIZE=${1:-29}; N=${2:-40}
@@ -9,7 +9,7 @@ python3 - <<PY
 import sys
 sys.path.insert(0, "$ROOT/tests")
 from synth import synth_bloom_words, write_blf
-write_blf("/tmp/rnd_bench.blf", synth_bloom_words(70001, 23, "a"))
+write_blf("/tmp/rnd_bench.blf", synth_bloom_words(7000003, 23, "a&(b|c)"))  # 56 MB at the design density: ~13 false positives per 2^32 keys
 PY
 t0=$(date +%s.%N)
 ECLOOP_HIP_RND_WINDOWS=$N ECLOOP_HIP_STATS=1 "$ROOT/ecloop_amd/host/ecloop-hip" rnd -f /tmp/rnd_bench.blf \
