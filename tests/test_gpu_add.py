@@ -255,3 +255,44 @@ def test_mult_verify_gtable_against_double_and_add():
             assert tuple(orc.hash160(x, y, True)) == got33[i]
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("n", [(1 << 18) + 77, (1 << 20) + 4099, (1 << 22) + (1 << 19) + 5])
+def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
+    """ecl_hip_mul_batch at sizes that select 1, 4 and 16 + 2 scalars per thread (one shared inversion per thread,
+    lib/ecc.c:695-707) and more than one staged chunk: with the all-ones filter every scalar comes back once, and every
+    hash160 must equal the one the double-and-add kernel + hash kernel give for the same scalar; scalars that are
+    0 (mod n) inside a batch are skipped without disturbing their neighbours' shared inversion."""
+    import ctypes as C
+    from ecloop_amd import Device, capi
+    rng = np.random.default_rng(n)
+    K = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, (n, 4), dtype=np.int64).astype(np.uint64)
+    zero_at = [5, n // 3, n - 1]
+    for i in zero_at:
+        K[i] = 0
+    K[7] = np.array([(orc.N >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)], dtype=np.uint64)  # n itself: also infinity
+    zero_at.append(7)
+    d = Device(0)
+    try:
+        d.set_bloom(ONES)
+        out = np.zeros(n, dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt))
+        assert rc == 0 and cnt.value == n - len(zero_at)
+        X, Y = np.zeros_like(K), np.zeros_like(K)
+        ok = np.zeros(n, dtype=np.uint8)
+        h33 = np.zeros((n, 5), dtype=np.uint32)
+        h65 = np.zeros((n, 5), dtype=np.uint32)
+        assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
+        assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
+    finally:
+        d.close()
+    recs = out[: cnt.value]
+    order = np.argsort(recs["key_offset"])
+    offs = recs["key_offset"][order]
+    want = np.setdiff1d(np.arange(n, dtype=np.uint64), np.array(zero_at, dtype=np.uint64))
+    assert np.array_equal(offs, want) and list(ok[zero_at]) == [0] * len(zero_at) and recs["compressed"].all()
+    assert np.array_equal(recs["h160"][order], h33[want.astype(np.int64)])
+    for i in (0, 1, n // 2):  # and the reference path itself against the oracle
+        k = sum(int(K[i][j]) << (64 * j) for j in range(4)) % orc.N
+        assert list(h33[i]) == orc.hash160(*orc.point_of(k), True)
