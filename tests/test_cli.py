@@ -339,3 +339,24 @@ def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
     for i in list(range(0, n, 9973)) + [n - 1, 1032444, 1032445, 1032446]:
         v = int.from_bytes(b[i].tobytes(), "big")
         assert int(out[i], 16) == (v - N if v >= N else v), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["add"], ["rnd", "-d", "64:64", "-seed", "w"]])
+def test_unbounded_scans_stream_instead_of_being_refused(cli, tmp_path, args):
+    """`add` without -r walks 0x800:p in 2^21-key jobs for ever (main.c:405-454, 668-672) and `rnd -d x:64` scans
+    2^64-key windows: neither key count fits 64 bits.  The host program hands the scan out chunk by chunk from a
+    256-bit counter: it must start, keep counting, and stop cleanly on SIGINT."""
+    import signal
+    import time
+    out = str(tmp_path / "o.txt")
+    pr = subprocess.Popen([cli] + args + ["-f", os.path.join(GOLD, "btc-puzzles-hash"), "-q", "-o", out], stdin=subprocess.DEVNULL,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    time.sleep(6)
+    assert pr.poll() is None, pr.stderr.read().decode(errors="replace")[-500:]
+    pr.send_signal(signal.SIGINT)
+    so, se = pr.communicate(timeout=60)
+    st = [s for s in se.decode(errors="replace").replace("\x1b[2K", "\r").split("\r") if "Mkeys/s" in s]
+    assert st and counts(st[-1].split("(")[0])[1] >= 1 << 33, st[-3:]
+    if args[0] == "add":  # the first keys of the default range hold four puzzle keys below 0x10000... none below 0x800: just a sanity check of the banner
+        assert b"range_s: 0000000000000000 0000000000000000 0000000000000000 0000000000000800" in so
