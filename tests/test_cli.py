@@ -360,3 +360,34 @@ def test_unbounded_scans_stream_instead_of_being_refused(cli, tmp_path, args):
     assert st and counts(st[-1].split("(")[0])[1] >= 1 << 33, st[-3:]
     if args[0] == "add":  # the first keys of the default range hold four puzzle keys below 0x10000... none below 0x800: just a sanity check of the banner
         assert b"range_s: 0000000000000000 0000000000000000 0000000000000000 0000000000000800" in so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["text", "bin"])
+def test_mul_fans_out_over_device_threads(cli, tmp_path, mode):
+    """`mul -t 4` (four device threads on the one GPU, ECLOOP_HIP_SHARE_GPU): an input of several 64 MB chunks - the
+    brainwallet keys of `make mul` twice, far apart, in 2.3 M filler lines - is parsed chunk by chunk and every chunk
+    goes to whichever device thread is idle (main.c:556-571).  Every key is found exactly as often as it occurs and the
+    counter equals the line count; the same through `-bin` (32-byte little-endian scalars)."""
+    from collections import Counter
+    bw = [l.strip() for l in open(os.path.join(GOLD, "btc-bw-priv")) if l.strip()]
+    rng = np.random.default_rng(12)
+    fill = ["%064x" % int.from_bytes(rng.bytes(32), "big") for _ in range(1000)]
+    n_fill = 1_150_000
+    blocks = [fill * (n_fill // 1000), bw, fill * (n_fill // 1000), bw]
+    lines_in = [l for b in blocks for l in b]
+    src = tmp_path / ("in." + mode)
+    if mode == "text":
+        src.write_text("\n".join(lines_in) + "\n")
+        extra = []
+    else:
+        N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+        src.write_bytes(b"".join((int(l, 16) % N).to_bytes(32, "little") for l in lines_in))
+        extra = ["-bin"]
+    env = dict(os.environ, ECLOOP_HIP_SHARE_GPU="4")
+    lines, status, stdout = run(cli, ["mul", "-f", os.path.join(GOLD, "btc-bw-hash"), "-a", "cu", "-t", "4"] + extra, stdin_path=str(src),
+                                out=str(tmp_path / "m.txt"), env=env)
+    assert "gpus: 4 " in stdout
+    c = Counter(lines)
+    assert len(c) == 1080 and set(c.values()) == {2} and digest(sorted(c)) == G["make_mul_bw"]["sha256_sorted"]
+    assert counts(status) == (2160, len(lines_in))
