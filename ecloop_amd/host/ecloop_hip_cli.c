@@ -239,7 +239,7 @@ typedef struct ctx_t {
   int ngpus;
   ecl_hip *dev[MAX_GPUS];
   u64 k_checked, k_found;
-  bool a33, a65, endo, quiet, use_color, raw_text, bin_input, parse_only, has_seed, finished;
+  bool a33, a65, endo, quiet, use_color, raw_text, bin_input, parse_only, plan_only, has_seed, finished;
   FILE *outfile;
   u64 ts_started, ts_updated, ts_printed;
   volatile bool paused; /* 'p' / 'r' on the terminal (main.c:41-46,874-888) */
@@ -452,8 +452,9 @@ static u64 scan_chunk(const ctx_t *ctx, const sc *hashed) {
   return c;
 }
 
-/* cmd_add (main.c:437-454) over [range_s, range_e): same keys hashed, same counters, spread over the GPUs */
-static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
+/* The plan of one scan: cmd_add (main.c:437-454) over [range_s, range_e) hashes the contiguous run of `hashed` keys from
+   range_s and adds `status_total` to the status counter (0: too long to count, added chunk by chunk). */
+static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
   sc span;
   sc_subraw(&span, &re, &rs);
   /* cmd_rnd always uses MAX_JOB_SIZE jobs, even for a narrower window (main.c:624) */
@@ -485,22 +486,27 @@ static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
     njobs = sc_u64(n);
   }
   u64 per_job = (job + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
-  scan_t sn;
-  memset(&sn, 0, sizeof sn);
-  sn.ctx = ctx, sn.rs = rs, sn.mult = ctx->endo ? 6 : 1;
-  pthread_mutex_init(&sn.mu, NULL);
+  memset(sn, 0, sizeof *sn);
+  sn->ctx = ctx, sn->rs = rs, sn->mult = ctx->endo ? 6 : 1;
   if (!(njobs.w[1] | njobs.w[2] | njobs.w[3]) && njobs.w[0] < (1ull << 40)) {
     /* the usual case: hashed = (njobs-1)*job + ceil(job/2048)*2048 keys, status counter = njobs*job (x6 with endo) */
-    sn.hashed = sc_u64((njobs.w[0] - 1) * job + per_job);
-    sn.status_total = njobs.w[0] * job * sn.mult;
+    sn->hashed = sc_u64((njobs.w[0] - 1) * job + per_job);
+    sn->status_total = njobs.w[0] * job * sn->mult;
   } else {
     /* astronomically long (e.g. the default range): hashed = njobs * 2^21 as a 256-bit count; it will not finish,
        and the status counter advances by the keys of every chunk */
     sc h = njobs;
     for (int i = 0; i < 21; ++i) sc_addraw(&h, &h, &h); /* njobs < 2^235 here: no wrap */
-    sn.hashed = h;
+    sn->hashed = h;
   }
-  sn.chunk = scan_chunk(ctx, &sn.hashed);
+  sn->chunk = scan_chunk(ctx, &sn->hashed);
+}
+
+/* one scan, spread over the GPUs */
+static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
+  scan_t sn;
+  scan_plan(ctx, rs, re, full_jobs, &sn);
+  pthread_mutex_init(&sn.mu, NULL);
   pthread_t th[MAX_GPUS];
   scan_worker_t ws[MAX_GPUS];
   for (int g = 0; g < ctx->ngpus; ++g) {
@@ -1252,6 +1258,7 @@ int main(int argc, const char **argv) {
       return 0;
     }
     if (!strcmp(argv[1], "add")) ctx.cmd = CMD_ADD;
+    if (!strcmp(argv[1], "plan")) ctx.cmd = CMD_ADD, ctx.plan_only = true;
     if (!strcmp(argv[1], "mul")) ctx.cmd = CMD_MUL;
     if (!strcmp(argv[1], "rnd")) ctx.cmd = CMD_RND;
   }
@@ -1267,7 +1274,7 @@ int main(int argc, const char **argv) {
     for (const char *c = seed; *c; ++c) s = s * 33 + (u8)*c;
     ctx.has_seed = true, srand(s); /* the reference free()s an argv pointer here and aborts (main.c:800-805) */
   }
-  load_filter(&ctx, arg_str(&args, "-f"));
+  if (!ctx.plan_only) load_filter(&ctx, arg_str(&args, "-f"));
   ctx.quiet = args_bool(&args, "-q");
   const char *outfile = arg_str(&args, "-o");
   if (outfile) ctx.outfile = fopen(outfile, "a");
@@ -1285,6 +1292,15 @@ int main(int argc, const char **argv) {
   load_offs_size(&ctx, &args);
   ctx.stride_k = sc_pow2(ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
 
+  if (ctx.plan_only) { /* hidden `plan`: the job arithmetic of `add` / `rnd` for -r / -d, no GPU (tests) */
+    scan_t sn;
+    ctx.ngpus = (int)args_uint(&args, "-t", 1);
+    scan_plan(&ctx, ctx.range_s, ctx.range_e, args_bool(&args, "-rnd"), &sn);
+    printf("ord_offs %u ord_size %u hashed %016llx%016llx%016llx%016llx status_total %llu chunk %llu\n", ctx.ord_offs, ctx.ord_size,
+           (unsigned long long)sn.hashed.w[3], (unsigned long long)sn.hashed.w[2], (unsigned long long)sn.hashed.w[1],
+           (unsigned long long)sn.hashed.w[0], (unsigned long long)sn.status_total, (unsigned long long)sn.chunk);
+    return 0;
+  }
   int have = ecl_hip_device_count(), real = have;
   /* test hook: ECLOOP_HIP_SHARE_GPU=N runs N device threads over the GPUs that exist (device g mod count), so the
      multi-GPU sharding / merging logic can be exercised on a one-GPU box */

@@ -391,3 +391,37 @@ def test_mul_fans_out_over_device_threads(cli, tmp_path, mode):
     c = Counter(lines)
     assert len(c) == 1080 and set(c.values()) == {2} and digest(sorted(c)) == G["make_mul_bw"]["sha256_sorted"]
     assert counts(status) == (2160, len(lines_in))
+
+
+def test_scan_plan_matches_the_oracles_job_loop(cli):
+    """the hidden `plan` command prints what scan_plan() derives from -r / -d: keys hashed and status counter of
+    cmd_add (main.c:405-454).  Compared with the oracle, which RUNS the reference's job loop (counter stepping by
+    job_size * stride until range_e, each job hashing ceil(job_size / 2048) * 2048 keys): sub-job ranges, ranges of a few
+    jobs, strides, ranges that end one scalar after a job boundary."""
+    import random
+    import orc
+    r = random.Random(77)
+    zero = orc.OrcFilter(bloom_words=np.zeros(8, np.uint64))
+    cases = [(0x8000, 0xFFFF, 0), (0x8000, 0x8001, 0), (0x801, 0x802, 0), (0x9000, 0x9801, 0), (0x800000, 0xFFFFFF, 0),
+             (0x8000, 0x8000 + (1 << 21), 0), (0x8000, 0x8001 + (1 << 21), 0), (0x8000, 0x7FFF + (1 << 21), 0)]
+    for _ in range(14):
+        offs = r.choice([0, 0, 1, 3, 7, 40, 128, 200])
+        a = r.randrange(1 << (offs + 33), 1 << (offs + 40))
+        keys = r.choice([1, 2, 100, 2047, 2048, 2049, 5000, 70000])
+        b = a + keys * (1 << offs) + (r.randrange(1 << offs) if offs and r.random() < 0.5 else 0)
+        cases.append((a, b, offs))
+    for a, b, offs in cases:
+        args = ["plan", "-r", f"{a:x}:{b:x}"] + (["-d", f"{offs}:32"] if offs else [])
+        out = subprocess.run([cli] + args, stdout=subprocess.PIPE, check=True).stdout.decode().split()
+        got = dict(zip(out[::2], out[1::2]))
+        eff = int(got["ord_offs"])
+        bits = max(20, b.bit_length())
+        assert eff == min(offs, max(1, bits - (bits if bits < 32 else 32))) if offs else eff == 0  # load_offs_size (main.c:703-746)
+        rc, _, n, checked, hashed = orc.add_range(zero, a, b, offs=eff, verify=False, threads=4)
+        assert rc == 0 and n == 0
+        assert int(got["hashed"], 16) == hashed and int(got["status_total"]) == checked, (hex(a), hex(b), offs, got, checked, hashed)
+    # -endo multiplies the counter by 6 (main.c:431); the default range is too long to count and is streamed
+    out = subprocess.run([cli, "plan", "-r", "8000:ffffff", "-endo"], stdout=subprocess.PIPE, check=True).stdout.decode().split()
+    assert out[out.index("status_total") + 1] == str(6 * 16777216)
+    out = subprocess.run([cli, "plan"], stdout=subprocess.PIPE, check=True).stdout.decode().split()
+    assert out[out.index("status_total") + 1] == "0" and int(out[out.index("hashed") + 1], 16) > 1 << 255
