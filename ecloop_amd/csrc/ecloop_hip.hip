@@ -670,9 +670,9 @@ static int default_lanes(ecl_hip* h) {
   hipDeviceProp_t p;
   HIPCHK(h, hipGetDeviceProperties(&p, h->dev));
   int occ = 0;
-  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)pick_add_kernel(h->flags), 256, 0));
+  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)pick_add_kernel(h->flags), ECL_ADD_BLOCK, 0));
   if (occ < 1) occ = 1;
-  const u32 resident = (u32)p.multiProcessorCount * (u32)occ * 256u;
+  const u32 resident = (u32)p.multiProcessorCount * (u32)occ * (u32)ECL_ADD_BLOCK;
   // Oversubscribe: with exactly the resident number of lanes every wave of the chip is in the same phase at the same
   // time (prefix products, then the inversion chain, then the hash-heavy walk back); with several times more blocks
   // than slots the dispatcher staggers them and the phases overlap.  Measured on addr33: 196608 lanes (resident)
@@ -873,7 +873,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   a.B = B, a.T = T, a.nb = nb, a.nkeys = nkeys;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(pick_add_kernel(h->flags), dim3(T / 256), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(pick_add_kernel(h->flags), dim3(T / ECL_ADD_BLOCK), dim3(ECL_ADD_BLOCK), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;
