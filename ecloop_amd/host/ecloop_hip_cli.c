@@ -672,6 +672,70 @@ static void *pack_worker(void *arg) {
   return NULL;
 }
 
+/* a pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n on the workers and
+   returns when all are done (64 MB chunks come every few milliseconds; creating 2 x 32 threads for each cost a quarter
+   of the front end's time) */
+typedef struct {
+  pthread_t th[32];
+  int nth;
+  void *(*fn)(void *);
+  char *args;
+  size_t stride;
+  int n, next, done;
+  u64 gen;
+  bool quit;
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+} pool_t;
+static void *pool_main(void *arg) {
+  pool_t *p = arg;
+  u64 seen = 0;
+  pthread_mutex_lock(&p->mu);
+  for (;;) {
+    while (!p->quit && (p->gen == seen || p->next >= p->n)) {
+      if (p->gen != seen && p->next >= p->n) seen = p->gen;
+      pthread_cond_wait(&p->cv_work, &p->mu);
+    }
+    if (p->quit) break;
+    int i = p->next++;
+    void *(*fn)(void *) = p->fn;
+    void *a = p->args + (size_t)i * p->stride;
+    pthread_mutex_unlock(&p->mu);
+    fn(a);
+    pthread_mutex_lock(&p->mu);
+    if (++p->done == p->n) pthread_cond_signal(&p->cv_done);
+  }
+  pthread_mutex_unlock(&p->mu);
+  return NULL;
+}
+static void pool_init(pool_t *p, int nth) {
+  memset(p, 0, sizeof *p);
+  pthread_mutex_init(&p->mu, NULL), pthread_cond_init(&p->cv_work, NULL), pthread_cond_init(&p->cv_done, NULL);
+  p->nth = nth;
+  for (int i = 0; i < nth; ++i) pthread_create(&p->th[i], NULL, pool_main, p);
+}
+static void pool_run(pool_t *p, void *(*fn)(void *), void *args, size_t stride, int n) {
+  if (n <= 0) return;
+  pthread_mutex_lock(&p->mu);
+  p->fn = fn, p->args = args, p->stride = stride, p->n = n, p->next = 0, p->done = 0, p->gen++;
+  pthread_cond_broadcast(&p->cv_work);
+  while (p->done < n) pthread_cond_wait(&p->cv_done, &p->mu);
+  pthread_mutex_unlock(&p->mu);
+}
+static void pool_stop(pool_t *p) {
+  pthread_mutex_lock(&p->mu);
+  p->quit = true;
+  pthread_cond_broadcast(&p->cv_work);
+  pthread_mutex_unlock(&p->mu);
+  for (int i = 0; i < p->nth; ++i) pthread_join(p->th[i], NULL);
+}
+typedef struct { void *dst; const void *src; size_t n; } copy_task;
+static void *copy_worker(void *arg) {
+  copy_task *t = arg;
+  memcpy(t->dst, t->src, t->n);
+  return NULL;
+}
+
 /* text chunks: reader thread -> parser */
 #define MUL_TEXT_CHUNK ((size_t)64 << 20)
 #define MUL_TEXT_RING 3
@@ -829,6 +893,8 @@ static void cmd_mul(ctx_t *ctx) {
   for (int g = 0; g < ctx->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
   parse_slice sl[32];
   memset(sl, 0, sizeof sl);
+  pool_t pool;
+  pool_init(&pool, P);
   for (;;) {
     pthread_mutex_lock(&tq.mu);
     while (!tq.count && !tq.eof) pthread_cond_wait(&tq.cv, &tq.mu);
@@ -841,12 +907,16 @@ static void cmd_mul(ctx_t *ctx) {
     int ai = sq.idle[--sq.nidle];
     pthread_mutex_unlock(&sq.mu);
     scalar_array *ar = &sq.arr[ai];
-    if (ctx->bin_input) {
+    if (ctx->bin_input) { /* the scalars as they are: into the page-locked array, P threads copying */
       ar->n = c->len / 32;
       ks_grow(ctx, ar, ar->n);
-      memcpy(ar->ks, c->buf, ar->n * 32);
+      copy_task ct[32];
+      size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
+      int nc = 0;
+      for (size_t at = 0; at < ar->n; at += per, ++nc)
+        ct[nc] = (copy_task){ar->ks + at, c->buf + at * 32, (ar->n - at < per ? ar->n - at : per) * 32};
+      pool_run(&pool, copy_worker, ct, sizeof ct[0], nc);
     } else {
-      pthread_t th[32];
       int ns = 0;
       size_t at = 0, end = c->len;
       for (int i = 0; i < P && at < end; ++i) { /* slices at line boundaries */
@@ -856,14 +926,14 @@ static void cmd_mul(ctx_t *ctx) {
         sl[ns].ctx = ctx, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
         at = stop, ns++;
       }
-      for (int i = 0; i < ns; ++i) pthread_create(&th[i], NULL, parse_worker, &sl[i]);
+      pool_run(&pool, parse_worker, sl, sizeof sl[0], ns);
       size_t total = 0;
-      for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL), total += sl[i].count;
+      for (int i = 0; i < ns; ++i) total += sl[i].count;
       ks_grow(ctx, ar, total);
       ar->n = total;
       size_t off = 0;
-      for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count, pthread_create(&th[i], NULL, pack_worker, &sl[i]);
-      for (int i = 0; i < ns; ++i) pthread_join(th[i], NULL);
+      for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count;
+      pool_run(&pool, pack_worker, sl, sizeof sl[0], ns);
     }
     pthread_mutex_lock(&tq.mu); /* the text buffer goes back to the reader */
     tq.tail = (tq.tail + 1) % MUL_TEXT_RING, tq.count--;
@@ -878,6 +948,7 @@ static void cmd_mul(ctx_t *ctx) {
   sq.done = true;
   pthread_cond_broadcast(&sq.cv);
   pthread_mutex_unlock(&sq.mu);
+  pool_stop(&pool);
   pthread_join(reader, NULL);
   for (int g = 0; g < ctx->ngpus; ++g) pthread_join(devth[g], NULL);
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);

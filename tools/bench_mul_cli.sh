@@ -1,11 +1,24 @@
 #!/bin/bash
-# `mul` end to end through the C host program: N seeded 64-hex-digit scalars on stdin (BASELINE.json configs[4]).
-N=${1:-4194304}
-python3 - "$N" > /tmp/mul_in.txt <<'PY'
-import sys, random
-r = random.Random(7)
-n = int(sys.argv[1])
-sys.stdout.write("".join("%064x\n" % r.getrandbits(256) for _ in range(n)))
-PY
+# `mul` end to end through the C host program (BASELINE.json configs[4]): N seeded 256-bit scalars on stdin, once as
+# 64-hex-digit lines (the reference's input format) and once as 32-byte little-endian scalars (`-bin`).
+#   bash tools/bench_mul_cli.sh [N=16777216]
+N=${1:-16777216}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-time "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -q -o /tmp/mul_out.txt < /tmp/mul_in.txt 2>&1 | tr '\r' '\n' | tail -1
+python3 - "$N" <<'PY'
+import sys
+import numpy as np
+n = int(sys.argv[1])
+b = np.frombuffer(np.random.default_rng(7).bytes(n * 32), dtype=np.uint8).reshape(n, 32)
+hexd = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
+t = np.empty((n, 65), dtype=np.uint8)
+t[:, 0:64:2], t[:, 1:64:2], t[:, 64] = hexd[b >> 4], hexd[b & 15], 10
+t.tofile("/tmp/mul_in.txt")
+b[:, ::-1].copy().tofile("/tmp/mul_in.bin")   # big-endian hex digits -> little-endian limbs
+PY
+for mode in txt bin; do
+  flag=""; [ $mode = bin ] && flag="-bin"
+  for rep in 1 2; do
+    /usr/bin/time -f "%e s wall" "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>&1 | tr '\r' '\n' | tail -2 | tr '\n' ' '
+    echo " [$mode, run $rep]"
+  done
+done
