@@ -18,7 +18,10 @@ PY
 for mode in txt bin; do
   flag=""; [ $mode = bin ] && flag="-bin"
   for rep in 1 2; do
-    /usr/bin/time -f "%e s wall" "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>&1 | tr '\r' '\n' | tail -2 | tr '\n' ' '
-    echo " [$mode, run $rep]"
+    t0=$(date +%s.%N)
+    "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>/tmp/mul_err.txt >/dev/null
+    t1=$(date +%s.%N)
+    st=$(tr '\r' '\n' < /tmp/mul_err.txt | grep Mkeys | tail -1)
+    echo "$mode run $rep, $N scalars: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s (process start-up and GPU bring-up included) | status line: $st"
   done
 done
