@@ -992,8 +992,9 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-    // scalars per thread: as many as keep >= 2^18 threads in flight (the chip holds 2^18 at 4 blocks per CU), at most MUL_R
-    u32 R = m >> 18;
+    // scalars per thread: as many as keep >= 2^17 threads in flight (two waves per SIMD hide the table gathers; the host
+    // program keeps two contexts per GPU busy, which fills the other half), at most MUL_R
+    u32 R = m >> 17;
     R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
     const u32 nt = (m + R - 1) / R;
     dim3 grid((nt + 255) / 256), blk(256);
