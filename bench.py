@@ -291,8 +291,9 @@ def bench_mul(args, rank, world, local, dist, barrier):
     if prof and prof.get("derived", {}).get("valu_lane_ops_per_scalar"):
         ops = prof["derived"]["valu_lane_ops_per_scalar"]
         ach = ops * nsc / (ms * 1e-3) / 1e12
-        res["roofline"].update({"achieved": round(ach, 3), "peak": round(PEAK_4CYCLE, 2), "unit": "T lane-ops/s", "frac": round(ach / PEAK_4CYCLE, 4),
-                                "valu_lane_ops_per_scalar": round(ops, 1), "profile": path})
+        res["roofline"].update({"achieved": round(ach, 3), "peak": round(PEAK_2CYCLE, 2), "unit": "T lane-ops/s", "frac": round(ach / PEAK_2CYCLE, 4),
+                                "frac_of_4_clock_issue": round(ach / PEAK_4CYCLE, 4), "valu_lane_ops_per_scalar": round(ops, 1), "profile": path,
+                                "note": "same peak as the add kernel's roofline (2-clock VALU issue); the multiplication-heavy window sums are mostly 4-clock+ opcodes"})
     print(json.dumps(res))
 
 
