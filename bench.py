@@ -336,10 +336,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        import datetime
+        patience = datetime.timedelta(seconds=300)  # a rank that aborts (failed check) must not leave the others waiting for long
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
 
