@@ -1,0 +1,93 @@
+"""Differential check of the oracle against the REAL reference program (oracle/_ref/ecloop_sane, built from the
+unmodified /root/reference by oracle/Makefile; it travels to the GPU box like the other built files): random ranges,
+strides, address types, endomorphism, filter kinds - found lists and status counters must be identical.  This is what
+lets the GPU fuzz and the large-size tests use the oracle as their yardstick beyond the committed golden vectors.
+Skipped where the binary is not present (it cannot be built without /root/reference)."""
+import os
+import random
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from synth import synth_bloom_words, write_blf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "ecloop_sane")
+GOLD = os.path.join(ROOT, "tests", "golden")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/ecloop_sane not built (needs /root/reference)")
+
+
+def run_ref(args, out):
+    if os.path.exists(out):
+        os.unlink(out)
+    pr = subprocess.run([REF] + args + ["-t", "1", "-q", "-o", out], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if pr.returncode != 0:
+        pytest.skip("the reference binary does not run on this host (%d): %s" % (pr.returncode, pr.stderr.decode(errors="replace")[-200:]))
+    status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1]
+    m = re.search(r"~ ([\d,.\s]+) / ([\d,.\s]+)", status)
+    clean = lambda s: int("".join(c for c in s if c.isdigit()))
+    lines = sorted(l.rstrip("\n") for l in open(out)) if os.path.exists(out) else []
+    return lines, clean(m.group(1)), clean(m.group(2))
+
+
+def test_random_add_runs_match_the_reference_binary(tmp_path):
+    r = random.Random(2024)
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    dense_words = synth_bloom_words(4099, 11, "a|b")
+    dense = str(tmp_path / "dense.blf")
+    write_blf(dense, dense_words)
+    puzzles = os.path.join(GOLD, "btc-puzzles-hash")
+    half_words = synth_bloom_words(70001, 23, "a")
+    half = str(tmp_path / "half.blf")
+    write_blf(half, half_words)
+    filters = [(ones, orc.OrcFilter(bloom_words=np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))), (dense, orc.OrcFilter(bloom_words=dense_words)),
+               (puzzles, orc.OrcFilter(hashes=[h for h in orc.parse_hash_list(puzzles) if h]))]
+    strided = (half, orc.OrcFilter(bloom_words=half_words))
+    out = str(tmp_path / "ref.txt")
+    for trial in range(14):
+        path, flt = filters[trial % 3]
+        offs = r.choice([0, 0, 0, 1, 9, 64, 128])
+        a33, a65 = r.choice([(True, False), (False, True), (True, True)])
+        endo = r.random() < 0.4
+        if offs:  # with a stride every job hashes 2^21 keys whatever the range (main.c:442): keep the hits few and the work small
+            (path, flt), endo = strided, False
+            a33, a65 = (True, False) if a33 else (False, True)
+        keys = r.choice([1, 7, 2047, 2048, 2049, 4500]) if path != puzzles else r.choice([30000, 70000])
+        a = r.randrange(1 << (offs + 33), 1 << (offs + 44)) if path != puzzles or offs else r.choice([0x8000, 0x20000, 0x900])
+        b = a + keys * (1 << offs)
+        args = ["add", "-f", path, "-r", f"{a:x}:{b:x}", "-a", ("c" if a33 else "") + ("u" if a65 else "")]
+        if offs:
+            args += ["-d", f"{offs}:32"]
+        if endo:
+            args.append("-endo")
+        lines, found, checked = run_ref(args, out)
+        bits = max(20, b.bit_length())
+        eff = min(offs, max(1, bits - min(bits, 32))) if offs else 0  # load_offs_size, main.c:703-746
+        rc, recs, n, ochecked, ohashed = orc.add_range(flt, a, b, a33=a33, a65=a65, endo=endo, offs=eff, threads=2, cap=1 << 17)
+        assert rc == 0
+        assert sorted(orc.found_lines(recs, n)) == lines, (trial, args)
+        assert (n, ochecked) == (found, checked), (trial, args)
+
+
+def test_mul_matches_the_reference_binary(tmp_path):
+    r = random.Random(5)
+    ks = [r.getrandbits(256) for _ in range(700)] + [1, 2, orc.N - 1, (1 << 14) - 1, 1 << 14, 1 << 255]
+    src = tmp_path / "k.txt"
+    src.write_text("".join("%064x\n" % k for k in ks))
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    out = str(tmp_path / "ref.txt")
+    pr = subprocess.run([REF, "mul", "-f", ones, "-a", "cu", "-t", "1", "-q", "-o", out], stdin=open(src, "rb"), stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=600)
+    if pr.returncode != 0:
+        pytest.skip("the reference binary does not run on this host")
+    lines = sorted(l.rstrip("\n") for l in open(out))
+    rc, recs, n = orc.mul_batch(orc.OrcFilter(bloom_words=np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64)), [k % orc.N for k in ks], a33=True, a65=True)
+    mine = sorted(orc.found_lines(recs, n))
+    # the reference's tail batch (main.c:467) also emits stale slots beyond the last key: compare the real keys' lines
+    want = [l for l in lines if int(l.split("\t")[2], 16) in {k % orc.N for k in ks}]
+    assert rc == 0 and sorted(set(want)) == sorted(set(mine)) and len(set(mine)) == 2 * len(set(k % orc.N for k in ks))
