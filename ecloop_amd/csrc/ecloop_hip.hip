@@ -513,9 +513,24 @@ int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
   return ECL_OK;
 }
 
+// Page-locking works on whole pages.  A small buffer shares its pages with whatever else the host allocator put there,
+// and registering / unregistering such a page under other host buffers that the runtime copies from or to ended in GPU
+// memory access faults on host heap addresses (tools/fuzz_mul_gpu.py, round 2: always a few calls after a 64-byte or
+// 2 KB array had been pinned).  Buffers below 1 MiB are therefore left alone - they gain nothing from DMA anyway - and
+// the pair of calls stays symmetric through a registry of what was really registered.
+#define ECL_PIN_MIN_BYTES ((size_t)1 << 20)
+static std::mutex g_pin_mu;
+static std::set<const void*> g_pinned;
 int ecl_hip_pin_host(const void* p, size_t bytes) {
   if (!p || !bytes) return ECL_E_ARG;
-  return hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess ? ECL_OK : ECL_E_HIP;
+  if (bytes < ECL_PIN_MIN_BYTES) return ECL_OK;
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return ECL_E_HIP;
+  }
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pinned.insert(p);
+  return ECL_OK;
 }
 void* ecl_hip_alloc_host(size_t bytes) {
   void* p = nullptr;
@@ -527,6 +542,10 @@ void ecl_hip_free_host(void* p) {
 }
 int ecl_hip_unpin_host(const void* p) {
   if (!p) return ECL_E_ARG;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_pinned.erase(p)) return ECL_OK;  // never registered (too small): nothing to undo
+  }
   return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? ECL_OK : ECL_E_HIP;
 }
 
@@ -963,8 +982,10 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   {
     hipPointerAttribute_t attr;
     memset(&attr, 0, sizeof attr);
-    if (hipPointerGetAttributes(&attr, scalars) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
-    else (void)hipGetLastError();
+    if ((size_t)n * 32 >= ECL_PIN_MIN_BYTES) {  // small batches are staged whatever their memory is
+      if (hipPointerGetAttributes(&attr, scalars) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+      else (void)hipGetLastError();
+    }
   }
   if (!direct)
     for (int i = 0; i < 2; ++i)

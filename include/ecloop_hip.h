@@ -77,7 +77,9 @@ int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 
 /* Optional: page-lock a host buffer (e.g. the bits about to be given to ecl_hip_set_bloom on several devices) so that
    the uploads run by DMA at PCIe rate, concurrently from one buffer; undo with ecl_hip_unpin_host.  Thin wrappers of
-   hipHostRegister / hipHostUnregister so that a plain-C host needs no HIP headers. */
+   hipHostRegister / hipHostUnregister so that a plain-C host needs no HIP headers.
+   Buffers below 1 MiB are accepted and left unpinned (page-locking acts on whole pages, which a small buffer shares with
+   unrelated host data); unpinning them is a no-op. */
 int ecl_hip_pin_host(const void *p, size_t bytes);
 int ecl_hip_unpin_host(const void *p);
 /* ... or get page-locked host memory to begin with (hipHostMalloc / hipHostFree): scalar arrays given to

@@ -44,6 +44,8 @@ def main():
         if mode == "ones" and n > (1 << 20):
             words = synth_bloom_words(nw, 7, "a|b")  # keep the record count of the big batches moderate
         pinned = rnd.random() < 0.5
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("trial", trials, dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned), flush=True)
         d = Device(0, a33=a33, a65=a65)
         try:
             d.set_bloom(words)
