@@ -296,3 +296,36 @@ def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
     for i in (0, 1, n // 2):  # and the reference path itself against the oracle
         k = sum(int(K[i][j]) << (64 * j) for j in range(4)) % orc.N
         assert list(h33[i]) == orc.hash160(*orc.point_of(k), True)
+
+
+def test_pinning_small_and_large_scalar_arrays():
+    """ecl_hip_pin_host / mul_batch with page-locked scalars: large arrays go by DMA from the caller's memory, arrays
+    below 1 MiB are accepted but left unpinned (registering heap pages that small buffers share with other host data
+    ended in GPU memory faults a few calls later - the pattern below, found by tools/fuzz_mul_gpu.py).  Results are
+    the same either way."""
+    import ctypes as C
+    from ecloop_amd import Device, capi
+    rng = np.random.default_rng(3)
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        big = rng.integers(1, 1 << 62, (1 << 17, 4), dtype=np.int64).astype(np.uint64)
+        out = np.zeros(2 * len(big), dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        assert d.lib.ecl_hip_mul_batch(d.h, big.ctypes.data, len(big), out.ctypes.data, len(out), C.byref(cnt)) == 0
+        ref = np.sort(out[: cnt.value], order=["key_offset", "compressed"])
+        assert cnt.value == 2 * len(big)
+        for it in range(150):
+            small = rng.integers(1, 1 << 62, (rng.integers(1, 70), 4), dtype=np.int64).astype(np.uint64)
+            assert d.lib.ecl_hip_pin_host(small.ctypes.data, small.nbytes) == 0
+            o = np.zeros(2 * len(small), dtype=capi.FOUND_DTYPE)
+            assert d.lib.ecl_hip_mul_batch(d.h, small.ctypes.data, len(small), o.ctypes.data, len(o), C.byref(cnt)) == 0 and cnt.value == 2 * len(small)
+            assert d.lib.ecl_hip_unpin_host(small.ctypes.data) == 0
+            if it % 30 == 0:  # the large array page-locked: same records as from pageable memory
+                assert d.lib.ecl_hip_pin_host(big.ctypes.data, big.nbytes) == 0
+                assert d.lib.ecl_hip_mul_batch(d.h, big.ctypes.data, len(big), out.ctypes.data, len(out), C.byref(cnt)) == 0
+                assert d.lib.ecl_hip_unpin_host(big.ctypes.data) == 0
+                assert np.array_equal(np.sort(out[: cnt.value], order=["key_offset", "compressed"]), ref)
+        assert d.lib.ecl_hip_unpin_host(big.ctypes.data) == 0  # not pinned any more: a no-op, not an error
+    finally:
+        d.close()
