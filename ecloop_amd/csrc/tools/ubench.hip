@@ -354,6 +354,58 @@ KCAL(k_cal_hashmix_g5, R4(I_ROT, 0) I_ROT(4) I_ROT(5) R4(I_AD3, 0) I_AD3(4) R4(I
 KCAL(k_cal_madrot, I_MAD(0) I_ROT(0) I_MAD(1) I_ROT(1) I_MAD(0) I_ROT(2) I_MAD(1) I_ROT(3) I_MAD(0) I_ROT(4) I_MAD(1) I_ROT(5) I_MAD(0) I_ROT(6) I_MAD(1) I_ROT(7) \
                    I_MAD(0) I_ROT(0) I_MAD(1) I_ROT(1) I_MAD(0) I_ROT(2) I_MAD(1) I_ROT(3) I_MAD(0) I_ROT(4) I_MAD(1) I_ROT(5) I_MAD(0) I_ROT(6) I_MAD(1) I_ROT(7))
 
+// do the double-rate runs of one wave survive next to OTHER waves of the SIMD issuing 4-clock instructions?  Waves with an
+// odd index on their SIMD run the add stream, the even ones the alignbit stream (blocks of 256 = 4 waves = one per SIMD,
+// so block parity decides).  If the two pipes did not interfere the mean would be (2.4 + 4.2) / 2.
+__global__ void k_mix_by_wave(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3);
+  if (blockIdx.x & 1) {
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+      }
+    }
+  } else {
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+      }
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+  if (s == 0x12345) out[0] = s;
+}
+// the same with the add waves at raised priority (s_setprio 3)
+__global__ void k_mix_by_wave_prio(uint32_t* out, uint32_t seed) {
+  uint32_t r[8], a = seed ^ threadIdx.x, b = a * 7 + 1;
+  for (int i = 0; i < 8; ++i) r[i] = a * (i + 3);
+  if (blockIdx.x & 1) {
+    __builtin_amdgcn_s_setprio(3);
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+      }
+    }
+  } else {
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+      }
+    }
+  }
+  uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+  if (s == 0x12345) out[0] = s;
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; double per_iter; };
 
@@ -381,6 +433,7 @@ int main(int argc, char** argv) {
       {"v_mad_u64_u32 dependent chain", k_mad_u64_dep, 32}, {"v_add_u32 dependent chain", k_add_dep, 32},
       {"mix 16 add + 16 alignbit, alternating", k_mix_alternating, 32}, {"mix 16 add + 16 alignbit, grouped by 8", k_mix_grouped, 32},
       {"mix 8 add + 24 alignbit (1:3)", k_mix_1to3, 32},
+      {"half the waves add, half alignbit", k_mix_by_wave, 32}, {"  same, add waves at s_setprio 3", k_mix_by_wave_prio, 32},
       // round 2: distinct source registers per chain; VOP2 float forms; more opcodes of the hash / limb arithmetic
       {"v_fmac_f32_e32  (distinct regs)", k_fmac_f32_e32, 32}, {"v_mul_f32_e32   (distinct regs)", k_mul_f32_e32, 32},
       {"v_add_f32_e32   (distinct regs)", k_add_f32_e32, 32}, {"v_fma_f32 VOP3  (distinct regs)", k_fma_f32_d, 32},
