@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — `add` (addr33) key-search throughput on MI355X: BASELINE.json's metric on its configs[1].
 
-    python bench.py [--gpus N --steps K --warmup W]              (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+        N>1 under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one rank per GPU;
+        N>1 WITHOUT a launcher: N device threads in this one process, one GPU each (same shards, same line).
+        Fewer visible GPUs than N is an error in both shapes.
 
 One step = one pass of the hot path over ONE contiguous range of 2^32 private keys from 0x1_0000_0000 against a
 `.blf`-format bloom filter resident in HBM: batch affine additions, SHA-256 -> RIPEMD-160 of every compressed public
 key, bloom probe, hits gathered on the host.  With N GPUs the range is cut into N contiguous shards, one per rank
 (north_star: "a 2^32 contiguous range at 1, 2, 4 and 8 MI355X") - strong scaling, no collective on the data path, only
-the timing barrier.  `weak_scaling` in the same line is a second, separately timed leg where every rank scans its own
+the timing rendezvous (barrier + MAX over workers; gloo by default, `--control nccl` for RCCL).  `weak_scaling` in the same line is a second, separately timed leg where every rank scans its own
 2^32 keys (`--scaling weak` makes that leg the headline instead).  Inputs are synthetic and already in HBM when the
 timed region starts: the filter holds 10^7 seeded pseudo-random hash160 values plus 16 planted keys per 2^32-key range
 (so the found list is not empty and is checked: a missing planted key or a found list that differs from the reference
@@ -65,7 +68,7 @@ def planted_offsets(nkeys):
     return [(nkeys // PLANTED) * i + 12345 * (i + 1) % 4096 for i in range(PLANTED)]
 
 
-def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1):
+def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1, cuda_index=0):
     """filter_n random entries + PLANTED keys in each of the `ranges` consecutive nkeys-key ranges from `start` -> bloom
     words resident on `dev` (identical on every rank: one .blf replicated per GPU).
     Above 5*10^7 entries (non-headline experiments, e.g. the ~6 GB filter of configs[2]) the bit array is filled with
@@ -74,11 +77,12 @@ def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1):
     size = blf_size_words(filter_n)
     if filter_n > 50_000_000:
         import torch
-        g = torch.Generator(device="cuda").manual_seed(2025)
+        cuda = f"cuda:{cuda_index}"
+        g = torch.Generator(device=cuda).manual_seed(2025)
         chunk, parts = 1 << 27, []
         for at in range(0, size, chunk):
             m = min(chunk, size - at)
-            a, b, c = (torch.randint(-(1 << 63), (1 << 63) - 1, (m,), dtype=torch.int64, device="cuda", generator=g) for _ in range(3))
+            a, b, c = (torch.randint(-(1 << 63), (1 << 63) - 1, (m,), dtype=torch.int64, device=cuda, generator=g) for _ in range(3))
             parts.append((a & (b | c)).cpu().numpy().view(np.uint64))
         dev.set_bloom(np.concatenate(parts))
     else:
@@ -92,26 +96,31 @@ def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1):
     return size, offs, h33
 
 
-def cpu_baseline(words, sample_keys_log2_max=33):
-    """The reference binary on this host's cores, same filter, same range start; bounded to ~10-30 s."""
+def cpu_baseline(words):
+    """The UNMODIFIED reference (oracle/_ref, built from /root/reference by oracle/Makefile) on this host's cores, same
+    filter, same range start, under every compiler flag set that runs here (SURVEY §7 "CPU baseline fairness": the
+    reference's own Makefile flags are pathological on some hosts, so one flag set is not a baseline):
+      ecloop_sane   -march=x86-64-v2 -msha -mno-avx*   (SHA-NI + scalar RIPEMD)          headline sample: 2^30 keys
+      ecloop_avx2   -march=x86-64-v3 -mno-sha          (portable SHA + AVX2 RIPEMD x8)   2^27 keys
+      ecloop_native -march=native (the reference Makefile's flags, built on the BUILD host's CPU; may not run here)
+    value = the best of them; bounded to ~10-40 s of CPU work in all.  Falls back to the oracle port if no binary runs."""
     cores = os.cpu_count() or 1
-    refs = [os.path.join(ROOT, "oracle", "_ref", n) for n in ("ecloop_sane", "ecloop_avx2")]
     from ecloop_amd.engine import blf_save
     tmp = tempfile.mkdtemp(prefix="eclbench")
     blf = os.path.join(tmp, "bench.blf")
     blf_save(blf, words)
 
-    def run(binary, log2n, threads):
+    def run(binary, log2n, threads, limit):
         out = os.path.join(tmp, "found.txt")
         if os.path.exists(out):
             os.unlink(out)
         end = RANGE_A + (1 << log2n) - 1
         t0 = time.time()
         pr = subprocess.run([binary, "add", "-f", blf, "-r", f"{RANGE_A:x}:{end:x}", "-t", str(threads), "-q", "-o", out],
-                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
         dt = time.time() - t0
         if pr.returncode != 0:
-            raise RuntimeError(f"reference exited with {pr.returncode}")
+            raise RuntimeError(f"exit status {pr.returncode}")
         status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
         m = re.search(r"([\d.]+)s ~ ([\d.]+) Mkeys/s", status)
         lines = sorted(l.strip() for l in open(out)) if os.path.exists(out) else []
@@ -120,34 +129,46 @@ def cpu_baseline(words, sample_keys_log2_max=33):
     import atexit
     import shutil
     atexit.register(shutil.rmtree, tmp, ignore_errors=True)
-    for binary in refs:
+    # the reference stops scaling at a few dozen threads (one mutex-guarded job counter + status line, main.c:419-431):
+    # measured on the 2x EPYC 9575F box 64 Mkeys/s at -t 32/64, 58 at 128, 44 at 256
+    threads = min(cores, 64)
+    sets, sample = [], None
+    for name, flags, log2n in (("ecloop_sane", "-O3 -ffast-math -march=x86-64-v2 -msha -mno-avx -mno-avx2 -mno-avx512f", 30),
+                               ("ecloop_avx2", "-O3 -ffast-math -march=x86-64-v3 -mno-sha", 27),
+                               ("ecloop_native", "-O3 -ffast-math -march=native (reference Makefile:3-8; native = the build host)", 27)):
+        binary = os.path.join(ROOT, "oracle", "_ref", name)
         if not os.path.exists(binary):
+            sets.append({"binary": name, "flags": flags, "error": "not built (no /root/reference at build time)"})
             continue
         try:
-            # the reference stops scaling at a few dozen threads (one mutex-guarded job counter + status line,
-            # main.c:419-431): measured on the 2x EPYC 9575F box 64 Mkeys/s at -t 32/64, 58 at 128, 44 at 256
-            threads = min(cores, 64)
-            log2n = 30
-            rate, secs, _, lines = run(binary, log2n, threads)
-            rate1, _, _, _ = run(binary, 25, 1)
-            return {"value": rate, "unit": "Mkeys/s", "cores": threads, "kind": "reference",
-                    "sample": f"{os.path.basename(binary)} add -r {RANGE_A:x}:+2^{log2n} same .blf, -t {threads} ({secs:.1f}s); -t 1: {rate1:.2f} Mkeys/s",
-                    "single_thread_mkeys": rate1}, (log2n, lines)
-        except Exception as e:  # SIGILL on a host without SHA-NI, missing binary, ...
-            sys.stderr.write(f"[bench] reference baseline {binary} failed: {e}\n")
+            rate, secs, _, lines = run(binary, log2n, threads, 180)
+            rate1, _, _, _ = run(binary, 24, 1, 120)
+            sets.append({"binary": name, "flags": flags, "mkeys": rate, "threads": threads, "keys_log2": log2n, "seconds": round(secs, 1),
+                         "single_thread_mkeys": rate1})
+            if sample is None:  # the found list of the first set that ran is what the GPU list is compared with
+                sample = (log2n, lines)
+        except Exception as e:  # SIGILL on a host without the instruction set, time limit, ...
+            sets.append({"binary": name, "flags": flags, "error": str(e)[:120]})
+            sys.stderr.write(f"[bench] reference baseline {name} failed: {e}\n")
+    ran = [x for x in sets if "mkeys" in x]
+    if ran:
+        best = max(ran, key=lambda x: x["mkeys"])
+        return {"value": best["mkeys"], "unit": "Mkeys/s", "cores": best["threads"], "kind": "reference",
+                "sample": f"{best['binary']} add -r {RANGE_A:x}:+2^{best['keys_log2']} same .blf, -t {best['threads']} ({best['seconds']}s); "
+                          f"-t 1: {best['single_thread_mkeys']:.2f} Mkeys/s; the other flag sets are in flag_sets",
+                "single_thread_mkeys": best["single_thread_mkeys"], "flag_sets": sets}, sample
     # fallback: the oracle port (same algorithm, plain C, pthreads)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
     import orc
     flt = orc.OrcFilter(bloom_words=words)
-    threads = min(cores, 64)
     log2n = 27
     t0 = time.time()
     rc, out, n, checked, hashed = orc.add_range(flt, RANGE_A, RANGE_A + (1 << log2n), verify=False, threads=threads)
     dt = time.time() - t0
     lines = sorted(orc.found_lines(out, n))
     return {"value": hashed / dt / 1e6, "unit": "Mkeys/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/orc.c add over 2^{log2n} keys, {threads} threads ({dt:.1f}s)"}, (log2n, lines)
+            "sample": f"oracle/orc.c add over 2^{log2n} keys, {threads} threads ({dt:.1f}s)", "flag_sets": sets}, (log2n, lines)
 
 
 # ----------------------------------------------------------------------------------------------- roofline inputs
@@ -236,16 +257,152 @@ def add_roofline(ms_launch, keys_per_launch):
     return r
 
 
+# ----------------------------------------------------------------------------------------------- the N workers of a run
+# The workload has no exchange step (contiguous shards, filter replicated, hits gathered on the host), so
+# the N>1 machinery is a rendezvous for the timed region and nothing else: barrier, MAX over workers, gather of small
+# host objects.  Two shapes, same worker code:
+#   * ranks   - one process per GPU under torch.distributed.run (how the driver launches N>1).  The rendezvous runs
+#               over gloo on CPU tensors by default: nothing of the hot path crosses it, and it is the backend the
+#               two-rank tests execute everywhere; `--control nccl` puts it on RCCL (device tensors) instead.
+#   * threads - `python bench.py --gpus N` WITHOUT a launcher: N host threads in this process, one device context each,
+#               the shape of the C host program's scan workers (ecloop_hip_cli.c: scan_worker; the reference's
+#               cmd_add_worker threads, main.c:405-435).  The library calls release the GIL.
+# Either way fewer visible GPUs than N is an error, never a silent n_gpus: 1.
+
+
+class Solo:
+    rank, world, kind = 0, 1, "single process"
+
+    def barrier(self):
+        pass
+
+    def allmax(self, x):
+        return float(x)
+
+    def gather(self, obj):
+        return [obj]
+
+    def close(self):
+        pass
+
+
+class Ranks:
+    kind = "torch.distributed.run: one process per GPU"
+
+    def __init__(self, control, local):
+        import datetime
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        patience = datetime.timedelta(seconds=300)  # a rank that aborts (failed check) must not leave the others waiting for long
+        if control == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
+            self.tdev = "cuda"
+        else:
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # the container hostname may not resolve
+            dist.init_process_group("gloo", timeout=patience)
+            self.tdev = "cpu"
+        self.kind += f", rendezvous over {control}"
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def allmax(self, x):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, obj)
+        return parts
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class Threads:
+    """rendezvous of N device threads in one process; an exception in one thread breaks the barrier for all"""
+    kind = "in-process device threads (no launcher)"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+        self._tls = threading.local()
+
+    def bind(self, rank):
+        self._tls.rank = rank
+
+    @property
+    def rank(self):
+        return self._tls.rank
+
+    def barrier(self):
+        self._bar.wait(timeout=600)
+
+    def _exchange(self, obj):
+        self._slots[self.rank] = obj
+        self._bar.wait(timeout=600)
+        out = list(self._slots)
+        self._bar.wait(timeout=600)
+        return out
+
+    def allmax(self, x):
+        return max(float(v) for v in self._exchange(x))
+
+    def gather(self, obj):
+        return self._exchange(obj)
+
+    def abort(self):
+        self._bar.abort()
+
+    def close(self):
+        pass
+
+
+def device_fence(dev_index, fake):
+    """torch.cuda.synchronize() on the worker's GPU: the library's calls already return after their stream has drained,
+    this is the contract's belt to those braces"""
+    if fake:
+        return
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(dev_index)
+
+
+def device_class():
+    """capi.Device - or, for the CPU tests of this file's N>1 plumbing only, the stand-in named by ECL_BENCH_DEVICE_CLS
+    ("module:Class", same surface; tests/fake_device.py).  Nothing in a normal run sets it."""
+    spec = os.environ.get("ECL_BENCH_DEVICE_CLS")
+    if not spec:
+        from ecloop_amd.capi import Device
+        return Device, False
+    import importlib
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls), True
+
+
+def visible_gpus(fake):
+    if fake:
+        return 1 << 20
+    from ecloop_amd import capi
+    return max(int(capi.load().ecl_hip_device_count()), 0)
+
+
 # ----------------------------------------------------------------------------------------------- mul (non-headline)
 
 
-def bench_mul(args, rank, world, local, dist, barrier):
-    import torch
+def bench_mul(args, sync, dev_index, emit):
     from ecloop_amd.engine import Filter, KeySearch
+    rank, world = sync.rank, sync.world
     n = 1 << args.mul_log2
     addr = args.addr if "--addr" in sys.argv else "cu"  # configs[4] / `make mul`: -a cu
-    args.addr = addr
-    ks = KeySearch(Filter(np.zeros(64, dtype=np.uint64)), device=local, a33="c" in addr, a65="u" in addr, verify=False)
+    ks = KeySearch(Filter(np.zeros(64, dtype=np.uint64)), device=dev_index, a33="c" in addr, a65="u" in addr, verify=False)
     rng = np.random.default_rng(1234 + rank)
     scal = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
     lib, h = ks.dev.lib, ks.dev.h
@@ -264,27 +421,25 @@ def bench_mul(args, rank, world, local, dist, barrier):
     for _ in range(max(args.warmup, 1)):
         step()
     ks.dev.reset_timing()
-    barrier()
+    device_fence(dev_index, False)
+    sync.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    device_fence(dev_index, False)
+    sync.barrier()
+    dt = sync.allmax(time.perf_counter() - t0)
     ms, calls, nsc = ks.dev.mul_timing()
     if rank != 0:
         return
-    hashes = len(args.addr)
+    hashes = len(addr)
     prof, path = load_profile("mul")
-    res = {"metric": f"M scalars/sec (mul -a {args.addr})", "value": round(n * world * args.steps / dt / 1e6, 2), "unit": "Mscalars/s", "n_gpus": world,
+    res = {"metric": f"M scalars/sec (mul -a {addr})", "value": round(n * world * args.steps / dt / 1e6, 2), "unit": "Mscalars/s", "n_gpus": world,
            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-           "config": {"workload": f"mul -a {args.addr}: 2^{args.mul_log2} seeded 256-bit scalars per GPU per step from HOST memory through "
+           "config": {"workload": f"mul -a {addr}: 2^{args.mul_log2} seeded 256-bit scalars per GPU per step from HOST memory through "
                                   "ecl_hip_mul_batch (copies overlapped with the kernel), empty filter", "hashes_per_scalar": hashes,
-                      "host_memory": "pageable (staged)" if args.pageable else "page-locked (direct DMA)"},
+                      "host_memory": "pageable (staged)" if args.pageable else "page-locked (direct DMA)", "launcher": sync.kind},
            "roofline": {"bound": "valu-int32", "kernel": "k_mul_check", "ms_per_call_on_stream": round(ms / max(calls, 1), 3),
                         "device_mscalars_s": round(nsc / (ms * 1e-3) / 1e6, 2) if ms else None,
                         "pcie_gbs": round(nsc * 32 / (ms * 1e-3) / 1e9, 2) if ms else None}}
@@ -294,7 +449,118 @@ def bench_mul(args, rank, world, local, dist, barrier):
         res["roofline"].update({"achieved": round(ach, 3), "peak": round(PEAK_2CYCLE, 2), "unit": "T lane-ops/s", "frac": round(ach / PEAK_2CYCLE, 4),
                                 "frac_of_4_clock_issue": round(ach / PEAK_4CYCLE, 4), "valu_lane_ops_per_scalar": round(ops, 1), "profile": path,
                                 "note": "same peak as the add kernel's roofline (2-clock VALU issue); the multiplication-heavy window sums are mostly 4-clock+ opcodes"})
-    print(json.dumps(res))
+    emit(res)
+
+
+# ----------------------------------------------------------------------------------------------- add (the headline)
+
+
+def bench_add(args, sync, dev_index, emit, t_process):
+    """one worker (rank or device thread): its shard of every leg on GPU `dev_index`; worker 0 reports"""
+    from ecloop_amd.engine import Filter, KeySearch, calc_priv, shard
+    rank, world = sync.rank, sync.world
+    Dev, fake = device_class()
+    nkeys = 1 << args.keys_log2
+    # per-worker scan of each leg: strong = shard `rank` of the one range, weak = the worker's own range
+    legs = {"strong": (RANGE_A + shard(nkeys, rank, world)[0], shard(nkeys, rank, world)[1]),
+            "weak": (RANGE_A + rank * nkeys, nkeys)}
+    order = [args.scaling] + ([m for m in ("strong", "weak") if m != args.scaling] if world > 1 and not args.no_second_leg else [])
+
+    # --- inputs -> HBM (untimed)
+    headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
+    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=dev_index, a33="c" in args.addr, a65="u" in args.addr,
+                   endo=args.endo, verify=True,
+                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes, device_cls=Dev)
+    size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.filter_n, ranges=world, cuda_index=dev_index)
+    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
+    for m in order:  # walk buffers allocated with the inputs, outside the timed region
+        ks.dev.reserve(min(legs[m][1], 1 << args.launch_log2))
+    t_setup = time.perf_counter() - t_process
+
+    def run_leg(mode, steps, warmup):
+        start, cnt = legs[mode]
+
+        def step():
+            ks.found.clear()
+            ks.add_keys(start, cnt)
+
+        for _ in range(warmup):
+            step()
+        ks.dev.reset_timing()
+        device_fence(dev_index, fake)
+        sync.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        device_fence(dev_index, fake)
+        mine_dt = time.perf_counter() - t0
+        sync.barrier()
+        dt = sync.allmax(time.perf_counter() - t0)
+        # correctness of what was just timed: every planted key inside this worker's scan is in the found list
+        found_pks = {r.pk for r in ks.found}
+        mine = [RANGE_A + r * nkeys + o for r in range(world) for o in planted_offs]
+        mine = [k for k in mine if start <= k < start + cnt]
+        missing = [hex(k) for k in mine if calc_priv(k, 1, 0, 0) not in found_pks]
+        if missing:
+            raise SystemExit(f"[bench] worker {rank} ({mode}): planted keys not found: {missing}")
+        kernel_ms, launches, kkeys = ks.dev.timing()
+        setup_ms, setups = ks.dev.setup_timing()
+        total = (nkeys if mode == "strong" else nkeys * world) * steps
+        shards = sync.gather({"gpu": dev_index, "worker": rank, "first_key": hex(start), "keys_per_step": cnt,
+                              "ms_per_step": round(mine_dt / steps * 1e3, 3), "kernel_ms_per_step": round(kernel_ms / steps, 3),
+                              "found_per_step": len(ks.found), "planted_checked": len(mine)})
+        return {"dt": dt, "value": total / dt / 1e6, "ms_per_step": dt / steps * 1e3, "kernel_ms": kernel_ms, "launches": launches,
+                "kkeys": kkeys, "setup_ms": setup_ms, "setups": setups, "planted_checked": len(mine), "found": len(ks.found),
+                "found_lines": sorted(r.line() for r in ks.found), "shards": shards}
+
+    out = {order[0]: run_leg(order[0], args.steps, args.warmup)}
+    for m in order[1:]:
+        out[m] = run_leg(m, min(args.steps, 5), 1)
+    sync.barrier()  # a worker that aborted above never gets here: the others time out in the barrier, they do not report
+    ks.close()
+    if rank != 0:
+        return
+
+    main_leg = out[order[0]]
+    ms_launch = main_leg["kernel_ms"] / max(main_leg["launches"], 1)
+    keys_per_launch = main_leg["kkeys"] / max(main_leg["launches"], 1)
+    per_gpu = legs[order[0]][1]
+    what = (f"ONE range of 2^{args.keys_log2} contiguous keys from 0x{RANGE_A:x} cut into {world} contiguous shard(s)" if order[0] == "strong"
+            else f"2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}")
+    res = {
+        "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})",
+        "value": round(main_leg["value"], 2), "unit": "Mkeys/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_leg["ms_per_step"], 3),
+        "higher_is_better": True, "scaling": order[0], "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"add addr33, {what}, .blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
+                   "keys_per_gpu_per_step": per_gpu, "parallelism": f"range-sharded x{world}, no collective", "launcher": sync.kind,
+                   "found_per_step": sum(x["found_per_step"] for x in main_leg["shards"]),
+                   "planted_checked": sum(x["planted_checked"] for x in main_leg["shards"]),
+                   "setup_ms_per_step_on_device": round(main_leg["setup_ms"] / args.steps, 3), "process_setup_s": round(t_setup, 2),
+                   "shards": main_leg["shards"]},
+        "roofline": add_roofline(ms_launch, keys_per_launch),
+    }
+    for m in order[1:]:
+        res[m + "_scaling"] = {"value": round(out[m]["value"], 2), "unit": "Mkeys/s", "ms_per_step": round(out[m]["ms_per_step"], 3),
+                               "steps": min(args.steps, 5), "keys_per_gpu_per_step": legs[m][1]}
+    if not headline:
+        hashes_per_key = len(args.addr) * (6 if args.endo else 1)
+        res["config"]["workload"] = res["config"]["workload"].replace("add addr33", f"add -a {args.addr}{' -endo' if args.endo else ''}")
+        res["config"]["hashes_per_key"] = hashes_per_key
+        res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: no PMC profile of this kernel is loaded", "ms_per_launch": round(ms_launch, 3),
+                           "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(main_leg["value"] * hashes_per_key / 1e3, 2)}
+    if fake:
+        res["data"] = "synthetic (TEST STAND-IN for the device: not a measurement)"
+    if world == 1 and not args.no_cpu and headline and not fake:
+        cb, (log2n, cpu_lines) = cpu_baseline(words)
+        res["cpu_baseline"] = cb
+        if log2n <= args.keys_log2:
+            gpu_lines = [l for l in main_leg["found_lines"] if int(l.split("\t")[2], 16) < RANGE_A + (1 << log2n)]
+            res["config"]["found_list_matches_cpu_on_sample"] = gpu_lines == cpu_lines
+            if gpu_lines != cpu_lines:
+                emit(res)
+                raise SystemExit(f"[bench] FOUND LIST MISMATCH on the CPU sample: gpu {len(gpu_lines)} lines, cpu {len(cpu_lines)} lines")
+    emit(res)
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -302,11 +568,13 @@ def bench_mul(args, rank, world, local, dist, barrier):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node; N>1 without a launcher runs N device threads in this process")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = ONE 2^keys-log2 range cut into N shards (default, the named config); weak = 2^keys-log2 keys per GPU")
+    ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
+                    help="ranks under torch.distributed.run: backend of the timing rendezvous (no data-path collective exists)")
     ap.add_argument("--keys-log2", type=int, default=32, help="keys per step (strong) / per GPU per step (weak); default 2^32 = the named config")
     ap.add_argument("--launch-log2", type=int, default=32, help="largest number of keys given to one device call")
     ap.add_argument("--half-group", type=int, default=0)
@@ -323,147 +591,69 @@ def main():
     t_process = time.perf_counter()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver (already set on the boxes)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    # test hook (not used by the driver): ECL_BENCH_SHARE_GPU=1 lets several ranks run on one GPU with the gloo
-    # backend, to exercise the N>1 code path on a single-GPU box
-    share = os.environ.get("ECL_BENCH_SHARE_GPU") == "1"
-    if share:
-        local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        import datetime
-        patience = datetime.timedelta(seconds=300)  # a rank that aborts (failed check) must not leave the others waiting for long
-        if share:
-            dist.init_process_group("gloo", timeout=patience)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
-
-    from ecloop_amd.build import build_library
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    launched = "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) >= 1 and "RANK" in os.environ
+    world = int(os.environ["WORLD_SIZE"]) if launched else (args.gpus or 1)
+    if world < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if launched and args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} contradicts the launcher's WORLD_SIZE {world}")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    _, fake = device_class()
+    if not fake and local == 0:
+        from ecloop_amd.build import build_library
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing
-    if dist is not None:
-        dist.barrier()
+    # test hook (not used by the driver): ECL_BENCH_SHARE_GPU=1 lets several workers run on the GPUs that exist
+    # (worker g on device g mod count), to exercise the N>1 code path on a single-GPU box
+    share = os.environ.get("ECL_BENCH_SHARE_GPU") == "1"
 
-    def barrier():
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def emit(res):
+        print(json.dumps(res), flush=True)
 
-    if args.cmd == "mul":
-        bench_mul(args, rank, world, local, dist, barrier)
-        if dist is not None:
-            dist.destroy_process_group()
+    def work(sync, dev_index):
+        if args.cmd == "mul":
+            bench_mul(args, sync, dev_index, emit)
+        else:
+            bench_add(args, sync, dev_index, emit, t_process)
+
+    if launched and world > 1:
+        sync = Ranks(args.control, local)  # rendezvous first: rank 0 has built the library by the time the others load it
+        sync.barrier()
+        have = visible_gpus(fake)
+        if have < world and not share:
+            raise SystemExit(f"[bench] {world} ranks but {have} GPU(s) visible: refusing to report n_gpus={world} (one rank per GPU)")
+        try:
+            work(sync, local % have if share else local)
+        finally:
+            sync.close()
         return
-
-    from ecloop_amd.engine import Filter, KeySearch, calc_priv, shard
-    nkeys = 1 << args.keys_log2
-    # per-rank scan of each leg: strong = shard `rank` of the one range, weak = the rank's own range
-    legs = {"strong": (RANGE_A + shard(nkeys, rank, world)[0], shard(nkeys, rank, world)[1]),
-            "weak": (RANGE_A + rank * nkeys, nkeys)}
-    order = [args.scaling] + ([m for m in ("strong", "weak") if m != args.scaling] if world > 1 and not args.no_second_leg else [])
-
-    # --- inputs -> HBM (untimed)
-    headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
-    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=local, a33="c" in args.addr, a65="u" in args.addr,
-                   endo=args.endo, verify=True,
-                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
-    size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.filter_n, ranges=world)
-    words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
-    for m in order:  # walk buffers allocated with the inputs, outside the timed region
-        ks.dev.reserve(min(legs[m][1], 1 << args.launch_log2))
-    t_setup = time.perf_counter() - t_process
-
-    def run_leg(mode, steps, warmup):
-        start, cnt = legs[mode]
-
-        def step():
-            ks.found.clear()
-            ks.add_keys(start, cnt)
-
-        for _ in range(warmup):
-            step()
-        ks.dev.reset_timing()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        # correctness of what was just timed: every planted key inside this rank's scan is in the found list
-        found_pks = {r.pk for r in ks.found}
-        mine = [RANGE_A + r * nkeys + o for r in range(world) for o in planted_offs]
-        mine = [k for k in mine if start <= k < start + cnt]
-        missing = [hex(k) for k in mine if calc_priv(k, 1, 0, 0) not in found_pks]
-        if missing:
-            raise SystemExit(f"[bench] rank {rank} ({mode}): planted keys not found: {missing}")
-        kernel_ms, launches, kkeys = ks.dev.timing()
-        setup_ms, setups = ks.dev.setup_timing()
-        total = (nkeys if mode == "strong" else nkeys * world) * steps
-        return {"dt": dt, "value": total / dt / 1e6, "ms_per_step": dt / steps * 1e3, "kernel_ms": kernel_ms, "launches": launches,
-                "kkeys": kkeys, "setup_ms": setup_ms, "setups": setups, "planted_checked": len(mine), "found": len(ks.found),
-                "found_lines": sorted(r.line() for r in ks.found)}
-
-    out = {order[0]: run_leg(order[0], args.steps, args.warmup)}
-    for m in order[1:]:
-        out[m] = run_leg(m, min(args.steps, 5), 1)
-    if dist is not None:  # a rank that aborted above never gets here: the others would hang in the barrier, not report
-        ok_flag = torch.tensor([1], device="cpu" if share else "cuda")
-        dist.all_reduce(ok_flag)
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+    have = visible_gpus(fake)
+    if have < world and not share:
+        raise SystemExit(f"[bench] --gpus {world} but {have} GPU(s) visible: refusing to run (one device thread per GPU)")
+    if world == 1:
+        work(Solo(), 0)
         return
+    import threading
+    sync = Threads(world)
+    errors = []
 
-    main_leg = out[order[0]]
-    ms_launch = main_leg["kernel_ms"] / max(main_leg["launches"], 1)
-    keys_per_launch = main_leg["kkeys"] / max(main_leg["launches"], 1)
-    per_gpu = legs[order[0]][1]
-    what = (f"ONE range of 2^{args.keys_log2} contiguous keys from 0x{RANGE_A:x} cut into {world} contiguous shard(s)" if order[0] == "strong"
-            else f"2^{args.keys_log2} contiguous keys per GPU from 0x{RANGE_A:x}")
-    res = {
-        "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})",
-        "value": round(main_leg["value"], 2), "unit": "Mkeys/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_leg["ms_per_step"], 3),
-        "higher_is_better": True, "scaling": order[0], "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"add addr33, {what}, .blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
-                   "keys_per_gpu_per_step": per_gpu, "parallelism": f"range-sharded x{world}, no collective",
-                   "found_per_step": main_leg["found"], "planted_checked": main_leg["planted_checked"],
-                   "setup_ms_per_step_on_device": round(main_leg["setup_ms"] / args.steps, 3), "process_setup_s": round(t_setup, 2)},
-        "roofline": add_roofline(ms_launch, keys_per_launch),
-    }
-    for m in order[1:]:
-        res[m + "_scaling"] = {"value": round(out[m]["value"], 2), "unit": "Mkeys/s", "ms_per_step": round(out[m]["ms_per_step"], 3),
-                               "steps": min(args.steps, 5), "keys_per_gpu_per_step": legs[m][1]}
-    if not headline:
-        hashes_per_key = len(args.addr) * (6 if args.endo else 1)
-        res["config"]["workload"] = res["config"]["workload"].replace("add addr33", f"add -a {args.addr}{' -endo' if args.endo else ''}")
-        res["config"]["hashes_per_key"] = hashes_per_key
-        res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: no PMC profile of this kernel is loaded", "ms_per_launch": round(ms_launch, 3),
-                           "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(main_leg["value"] * hashes_per_key / 1e3, 2)}
-    if world == 1 and not args.no_cpu and headline:
-        cb, (log2n, cpu_lines) = cpu_baseline(words)
-        res["cpu_baseline"] = cb
-        if log2n <= args.keys_log2:
-            gpu_lines = [l for l in main_leg["found_lines"] if int(l.split("\t")[2], 16) < RANGE_A + (1 << log2n)]
-            res["config"]["found_list_matches_cpu_on_sample"] = gpu_lines == cpu_lines
-            if gpu_lines != cpu_lines:
-                print(json.dumps(res))
-                raise SystemExit(f"[bench] FOUND LIST MISMATCH on the CPU sample: gpu {len(gpu_lines)} lines, cpu {len(cpu_lines)} lines")
-    print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+    def body(g):
+        sync.bind(g)
+        try:
+            work(sync, g % have if share else g)
+        except BaseException as e:  # SystemExit of a failed check included: release the others, report, fail the run
+            errors.append((g, e))
+            sync.abort()
+
+    th = [threading.Thread(target=body, args=(g,), name=f"gpu{g}") for g in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    real = [(g, e) for g, e in errors if not isinstance(e, threading.BrokenBarrierError)]
+    if errors:
+        for g, e in real or errors:
+            sys.stderr.write(f"[bench] device thread {g}: {e!r}\n")
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

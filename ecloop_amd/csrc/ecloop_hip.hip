@@ -971,7 +971,9 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
       if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
       h->d_multmp = nullptr, h->kbuf_cap = 0;
       for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
-      HIPCHK(h, hipMalloc(&h->d_multmp, (size_t)want * 36 * sizeof(u32)));
+      // the kernel indexes the planes as r * 36 * nt + plane * nt + t with R * nt = m rounded up to a multiple of R:
+      // up to R - 1 slots more than m, so the buffer carries MUL_R spare slots
+      HIPCHK(h, hipMalloc(&h->d_multmp, ((size_t)want + MUL_R) * 36 * sizeof(u32)));
       h->kbuf_cap = want;
     }
   }
@@ -1038,7 +1040,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
 }
 
 extern "C" int ecl_hip_verify(ecl_hip* h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h33)[5], uint32_t (*h65)[5], uint8_t* ok) {
-  if (!h || !k || !h33 || !h65 || !ok || n == 0) return ECL_E_ARG;
+  if (!h || !k || !h33 || !h65 || !ok || n == 0 || n > (1u << 31)) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
@@ -1295,7 +1297,7 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   h->B = saveB, h->Tmax = saveT, h->B_auto = saveAuto;
   if (h->d_tab) (void)hipFree(h->d_tab);
   h->d_tab = nullptr, h->tab_B = 0, h->walk_valid = false;
-  h->kernel_ms = 0, h->launches = 0, h->keys = 0;
+  h->kernel_ms = 0, h->launches = 0, h->keys = 0, h->setup_ms = 0, h->setups = 0;
   if (rc != ECL_OK) return rc;
   u32 seen = 0;
   bool good = n == cap;
@@ -1310,6 +1312,33 @@ extern "C" int ecl_hip_selftest(ecl_hip* h) {
   if (!good || seen != N * per_key) {
     h->err = "walk kernel disagrees with the double-and-add kernel";
     return ECL_E_SELFTEST;
+  }
+  // (3) the window-table sum (gtable_mul: ecl_hip_verify, the base centre of every non-contiguous walk, `mul`) against the
+  // double-and-add kernel on full-width scalars, so that every one of the 19 windows carries a digit: the walk's base
+  // centre and the verification of its hits share this function and the table, and a hit shares its high digits with
+  // the base centre - (2) exercises only the low windows.  Scalars: a fixed xorshift stream, plus every digit at its
+  // maximum (0x3fff in all windows) and a single top-window digit.
+  {
+    const u32 M = 48;
+    std::vector<uint64_t> vk((size_t)M * 4), vx((size_t)M * 4), vy((size_t)M * 4);
+    std::vector<uint32_t> w33((size_t)M * 5), w65((size_t)M * 5), g33((size_t)M * 5), g65((size_t)M * 5);
+    std::vector<uint8_t> vok(M), gok(M);
+    u64 z = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < vk.size(); ++i) {
+      z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+      vk[i] = z;
+    }
+    for (int w = 0; w < 4; ++w) vk[w] = ~0ull;                 // all digits 0x3fff (the sum is (2^256 - 1) mod n times G)
+    vk[4] = 0, vk[5] = 0, vk[6] = 0, vk[7] = 1ull << 60;       // window 18 only
+    rc = ecl_hip_verify(h, (const uint64_t(*)[4])vk.data(), M, (uint32_t(*)[5])g33.data(), (uint32_t(*)[5])g65.data(), gok.data());
+    if (rc == ECL_OK) rc = ecl_hip_diag_mulg(h, (const uint64_t(*)[4])vk.data(), (uint64_t(*)[4])vx.data(), (uint64_t(*)[4])vy.data(), vok.data(), M);
+    if (rc == ECL_OK) rc = ecl_hip_diag_hash160(h, (const uint64_t(*)[4])vx.data(), (const uint64_t(*)[4])vy.data(),
+                                                (uint32_t(*)[5])w33.data(), (uint32_t(*)[5])w65.data(), M);
+    if (rc != ECL_OK) return rc;
+    if (g33 != w33 || g65 != w65 || gok != vok) {
+      h->err = "window-table scalar multiplication disagrees with the double-and-add kernel";
+      return ECL_E_SELFTEST;
+    }
   }
   return ECL_OK;
 }

@@ -234,12 +234,13 @@ class KeySearch:
     """ctx_t + cmd_add / cmd_mul for one GPU."""
 
     def __init__(self, flt, device=0, a33=True, a65=False, endo=False, ord_offs=0, verify=True, launch_keys=1 << 32,
-                 half_group=0, max_lanes=0):
+                 half_group=0, max_lanes=0, device_cls=None):
         if not (a33 or a65):
             a33 = True  # main.c:825-827
         self.flt, self.a33, self.a65, self.endo, self.offs, self.verify = flt, a33, a65, endo, ord_offs, verify
         self.stride = 1 << ord_offs
-        self.dev = Device(device, a33=a33, a65=a65, endo=endo, ord_offs=ord_offs)
+        # device_cls: the GPU context (capi.Device); the CPU tests of the host logic pass a stand-in with the same surface
+        self.dev = (device_cls or Device)(device, a33=a33, a65=a65, endo=endo, ord_offs=ord_offs)
         if half_group or max_lanes:
             self.dev.set_geometry(half_group, max_lanes)
         self.dev.set_bloom(flt.words)
@@ -253,7 +254,8 @@ class KeySearch:
     def close(self):
         self.dev.close()
 
-    # pk_verify_hash (main.c:248-263): re-derive the hit from its scalar on a path that shares no kernel with the walk
+    # pk_verify_hash (main.c:248-263): re-derive the hit from its scalar by the window-table sum (not the walk kernel;
+    # the self-test of the context pins that sum against the double-and-add kernel)
     def _verify(self, recs):
         if not recs:
             return

@@ -1297,6 +1297,18 @@ static u64 usnow(void) {
   gettimeofday(&tv, NULL);
   return (u64)tv.tv_sec * 1000000 + tv.tv_usec;
 }
+/* Device contexts of a run: context g works on GPU (g mod shown) mod real, where `shown` is the -t count clamped to
+   the visible GPUs and `real` the GPUs that exist.  `mul` opens TWO contexts per GPU - a batch is one synchronous
+   ecl_hip_mul_batch call (scalars over PCIe, then the kernel), so the second context's copy runs under the first one's
+   kernel and the other way round (290 -> 4xx M scalars/s from the same parsed stream, tools/bench_mul_cli.sh) - and the
+   two contexts of a pair land on the SAME GPU, never on one the user did not ask for.  Returns the context count. */
+static int context_devices(int cmd, int shown, int real, int dev_of[MAX_GPUS]) {
+  int n = shown;
+  if (cmd == CMD_MUL && 2 * n <= MAX_GPUS) n *= 2;
+  for (int g = 0; g < n; ++g) dev_of[g] = (g % shown) % real;
+  return n;
+}
+
 static void *open_worker(void *arg) {
   open_job *j = arg;
   ctx_t *ctx = j->ctx;
@@ -1366,6 +1378,14 @@ int main(int argc, const char **argv) {
   if (ctx.plan_only) { /* hidden `plan`: the job arithmetic of `add` / `rnd` for -r / -d, no GPU (tests) */
     scan_t sn;
     ctx.ngpus = (int)args_uint(&args, "-t", 1);
+    if (arg_str(&args, "-visible")) { /* the context -> GPU map of `-t N` on a box with that many GPUs */
+      int real = (int)args_uint(&args, "-visible", 1), shown = ctx.ngpus > real ? real : ctx.ngpus, dev_of[MAX_GPUS];
+      int n = context_devices(args_bool(&args, "-mul") ? CMD_MUL : CMD_ADD, shown, real, dev_of);
+      printf("contexts %d gpus %d devices", n, shown);
+      for (int g = 0; g < n; ++g) printf(" %d", dev_of[g]);
+      printf("\n");
+      return 0;
+    }
     scan_plan(&ctx, ctx.range_s, ctx.range_e, args_bool(&args, "-rnd"), &sn);
     printf("ord_offs %u ord_size %u hashed %016llx%016llx%016llx%016llx status_total %llu chunk %llu\n", ctx.ord_offs, ctx.ord_size,
            (unsigned long long)sn.hashed.w[3], (unsigned long long)sn.hashed.w[2], (unsigned long long)sn.hashed.w[1],
@@ -1380,11 +1400,8 @@ int main(int argc, const char **argv) {
   u64 want = args_uint(&args, "-t", (u64)have);
   ctx.ngpus = (int)(want < 1 ? 1 : want > (u64)have ? (u64)have : want);
   if (ctx.ngpus > MAX_GPUS) ctx.ngpus = MAX_GPUS;
-  int gpus_shown = ctx.ngpus;
-  /* `mul`: two device threads (two contexts) per GPU - a batch is one synchronous ecl_hip_mul_batch call (scalars over
-     PCIe, then the kernel), so a second context keeps the copy engine busy under the first one's kernel and the other
-     way round: 290 -> 4xx M scalars/s from the same parsed stream (tools/bench_mul_cli.sh) */
-  if (ctx.cmd == CMD_MUL && 2 * ctx.ngpus <= MAX_GPUS) ctx.ngpus *= 2;
+  int gpus_shown = ctx.ngpus, dev_of[MAX_GPUS];
+  ctx.ngpus = context_devices(ctx.cmd, gpus_shown, real, dev_of);
   /* Device bring-up, all GPUs at once (one host thread each): context, filter upload from the one pinned host copy
      (every GPU over its own PCIe link), optional list, and the walk buffers of the chunks this scan will hand out -
      all before the clock of the status line starts; the time it took is printed in the banner. */
@@ -1407,7 +1424,7 @@ int main(int argc, const char **argv) {
       if (!(hashed.w[1] | hashed.w[2] | hashed.w[3]) && hashed.w[0] < share) share = hashed.w[0];
     }
     for (int g = 0; g < ctx.ngpus; ++g) {
-      jobs[g] = (open_job){&ctx, g, g % real, (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0), share, ECL_OK};
+      jobs[g] = (open_job){&ctx, g, dev_of[g], (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0), share, ECL_OK};
       pthread_create(&th[g], NULL, open_worker, &jobs[g]);
     }
     for (int g = 0; g < ctx.ngpus; ++g) pthread_join(th[g], NULL);

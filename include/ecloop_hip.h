@@ -123,7 +123,9 @@ int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_
                       uint32_t *nout);
 
 /* pk_verify_hash (main.c:248-263) for n reported private keys in one go: both hash160 values of k*G, derived on the
-   device by a path that shares no kernel with the walk (fixed-base window sum + own inversion per key); ok[i] = 0
+   device by a path other than the walk kernel (fixed-base window sum + own inversion per key).  The window sum and its
+   table also give the base centre of a non-contiguous walk, and a hit shares its high digits with that centre, so
+   the context self-test checks the window sum against the double-and-add kernel on full-width scalars.  ok[i] = 0
    for k = 0 (mod n).  The caller compares with the hit's h160 and treats a mismatch as fatal, like the reference. */
 int ecl_hip_verify(ecl_hip *h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h33)[5], uint32_t (*h65)[5], uint8_t *ok);
 

@@ -425,3 +425,18 @@ def test_scan_plan_matches_the_oracles_job_loop(cli):
     assert out[out.index("status_total") + 1] == str(6 * 16777216)
     out = subprocess.run([cli, "plan"], stdout=subprocess.PIPE, check=True).stdout.decode().split()
     assert out[out.index("status_total") + 1] == "0" and int(out[out.index("hashed") + 1], 16) > 1 << 255
+
+
+def test_context_to_gpu_map(cli):
+    """which GPU each device context opens (hidden `plan -visible R [-mul]`, no GPU needed): `add` / `rnd` one context per
+    GPU of `-t`; `mul` two contexts per GPU, both on the SAME GPU and never on one beyond `-t` (round-2 advisor finding:
+    `-t 1` on an 8-GPU box put the second context on GPU 1)."""
+    def devmap(*a):
+        out = subprocess.run([cli, "plan", "-r", "8000:ffff"] + list(a), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+        return int(out[1]), int(out[3]), [int(x) for x in out[5:]]
+    assert devmap("-t", "1", "-visible", "8", "-mul") == (2, 1, [0, 0])
+    assert devmap("-t", "3", "-visible", "8", "-mul") == (6, 3, [0, 1, 2, 0, 1, 2])
+    assert devmap("-t", "8", "-visible", "8", "-mul") == (16, 8, list(range(8)) * 2)
+    assert devmap("-t", "8", "-visible", "8") == (8, 8, list(range(8)))
+    assert devmap("-t", "8", "-visible", "2") == (2, 2, [0, 1])
+    assert devmap("-t", "4", "-visible", "1", "-mul") == (2, 1, [0, 0])

@@ -298,6 +298,36 @@ def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
         assert list(h33[i]) == orc.hash160(*orc.point_of(k), True)
 
 
+@pytest.mark.parametrize("n", [(1 << 19) - 1, (1 << 20) - 3, (1 << 20) - 1, (1 << 21) - 1])
+def test_mul_batch_sizes_just_below_a_power_of_two(n):
+    """ecl_hip_mul_batch with n one to three below 2^19 / 2^20 / 2^21 on a FRESH context: the scalars-per-thread count R
+    (3, 7, 7, 15) does not divide n, so R * ceil(n / R) exceeds the power-of-two capacity the parking buffer used to be
+    sized for and the last plane landed outside it (round-2 advisor finding).  Every scalar must come back once with
+    the double-and-add kernel's hash."""
+    import ctypes as C
+    from ecloop_amd import Device, capi
+    rng = np.random.default_rng(n)
+    K = rng.integers(1, 1 << 62, (n, 4), dtype=np.int64).astype(np.uint64)
+    d = Device(0)
+    try:
+        d.set_bloom(ONES)
+        out = np.zeros(n, dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        assert d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt)) == 0 and cnt.value == n
+        tail = np.arange(n - 4096, n)
+        X, Y = np.zeros((4096, 4), np.uint64), np.zeros((4096, 4), np.uint64)
+        h33, h65 = np.zeros((4096, 5), np.uint32), np.zeros((4096, 5), np.uint32)
+        Kt = np.ascontiguousarray(K[tail])
+        assert d.lib.ecl_hip_diag_mulg(d.h, Kt.ctypes.data, X.ctypes.data, Y.ctypes.data, None, 4096) == 0
+        assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, 4096) == 0
+    finally:
+        d.close()
+    recs = out[: cnt.value]
+    order = np.argsort(recs["key_offset"])
+    assert np.array_equal(recs["key_offset"][order], np.arange(n, dtype=np.uint64))
+    assert np.array_equal(recs["h160"][order][tail], h33)  # the scalars parked in the last plane
+
+
 def test_pinning_small_and_large_scalar_arrays():
     """ecl_hip_pin_host / mul_batch with page-locked scalars: large arrays go by DMA from the caller's memory, arrays
     below 1 MiB are accepted but left unpinned (registering heap pages that small buffers share with other host data

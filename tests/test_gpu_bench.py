@@ -1,6 +1,7 @@
-"""bench.py on the GPU box: the JSON contract at N=1, and the N>1 code path with two ranks - over RCCL when two GPUs
-are visible, else two ranks sharing the one GPU over gloo (ECL_BENCH_SHARE_GPU=1), so the sharded legs, the barrier /
-MAX-over-ranks timing and the planted-key checks of every rank run either way."""
+"""bench.py on the GPU box: the JSON contract at N=1, and the N>1 code path in both shapes - `--gpus 2` with no launcher
+(two device threads) and two ranks under torch.distributed.run (rendezvous over gloo, and over RCCL when two GPUs are
+visible).  On a one-GPU box the two workers share the GPU (ECL_BENCH_SHARE_GPU=1), so the sharded legs, the barrier /
+MAX-over-workers timing and the planted-key checks of every worker run either way."""
 import json
 import os
 import subprocess
@@ -35,19 +36,55 @@ def test_bench_line_single_gpu_small():
         assert "matches_build" in rf["profile"] and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=2e-3)
 
 
-def test_bench_two_ranks_strong_and_weak_legs():
+def check_two(r, launcher):
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["keys_per_gpu_per_step"] == 1 << 26
+    assert launcher in r["config"]["launcher"]
+    assert abs(r["value"] - (1 << 27) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3
+    sh = sorted(r["config"]["shards"], key=lambda x: x["worker"])
+    assert [x["keys_per_step"] for x in sh] == [1 << 26, 1 << 26] and sum(x["planted_checked"] for x in sh) == 16
+    w = r["weak_scaling"]
+    assert w["keys_per_gpu_per_step"] == 1 << 27 and abs(w["value"] - 2 * (1 << 27) / (w["ms_per_step"] * 1e3)) / w["value"] < 1e-3
+    assert "cpu_baseline" not in r  # worker 0 at N=1 only
+
+
+def two_gpu_env():
     import torch
     two = torch.cuda.device_count() >= 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if not two:
-        env["ECL_BENCH_SHARE_GPU"] = "1"
+        env["ECL_BENCH_SHARE_GPU"] = "1"  # both workers on the one GPU of this box
+    return env, two
+
+
+SMALL2 = ["--gpus", "2", "--keys-log2", "27", "--steps", "2", "--warmup", "1"]
+
+
+def test_bench_gpus_2_without_a_launcher():
+    """`python bench.py --gpus 2`, nothing else: two device threads in one process (two GPUs if the box has them)"""
+    env, _ = two_gpu_env()
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL2, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        timeout=1200, cwd=ROOT, env=env)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    check_two(last_json(pr.stdout), "in-process device threads")
+
+
+@pytest.mark.parametrize("control", ["gloo", "nccl"])
+def test_bench_two_ranks_strong_and_weak_legs(control):
+    """the driver's N>1 form: torch.distributed.run, one rank per GPU; the rendezvous over gloo (default) and over RCCL
+    (needs two real GPUs: RCCL refuses two ranks on one device)"""
+    env, two = two_gpu_env()
+    if control == "nccl" and not two:
+        pytest.skip("one GPU on this box: RCCL cannot host two ranks on it")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--keys-log2", "27", "--steps", "2", "--warmup", "1"]
+           "--master-port", "29517" if control == "gloo" else "29519", os.path.join(ROOT, "bench.py"), "--control", control] + SMALL2
     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, cwd=ROOT, env=env)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
-    r = last_json(pr.stdout)
-    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["keys_per_gpu_per_step"] == 1 << 26
-    assert abs(r["value"] - (1 << 27) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3
-    w = r["weak_scaling"]
-    assert w["keys_per_gpu_per_step"] == 1 << 27 and abs(w["value"] - 2 * (1 << 27) / (w["ms_per_step"] * 1e3)) / w["value"] < 1e-3
-    assert "cpu_baseline" not in r  # rank 0 at N=1 only
+    check_two(last_json(pr.stdout), "torch.distributed.run")
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import torch
+    n = torch.cuda.device_count() + 1
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--keys-log2", "24", "--no-cpu"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert pr.returncode != 0 and b"GPU(s) visible" in pr.stderr and not pr.stdout.strip()
