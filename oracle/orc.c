@@ -785,6 +785,7 @@ int orc_add_range(const orc_add_cfg *cfg, const orc_filter *flt, const orc_fe ra
   orc_fe span;
   orc_sn_sub(span, range_e, range_s);
   st.job_size = (span[1] | span[2] | span[3]) == 0 && span[0] < MAX_JOB ? span[0] : MAX_JOB; /* main.c:442 */
+  if (cfg->rnd_jobs) st.job_size = MAX_JOB; /* cmd_rnd runs the same workers with full-size jobs (main.c:624,645-651) */
   int nt = cfg->threads < 1 ? 1 : cfg->threads;
   if (nt == 1) add_worker(&st);
   else {

@@ -94,6 +94,7 @@ typedef struct orc_add_cfg {
   uint32_t ord_offs;     /* stride = 2^ord_offs (main.c:221-222) */
   int verify;            /* re-derive every hit like pk_verify_hash (main.c:248-263); mismatch -> return -2 */
   int threads;           /* >=1; with >1 the found order is nondeterministic, like the reference */
+  int rnd_jobs;          /* 1: one window of cmd_rnd - job_size is MAX_JOB_SIZE whatever the range (main.c:624) */
 } orc_add_cfg;
 
 /* cmd_add (main.c:405-454) over [range_s, range_e): returns 0, -1 on found overflow, -2 on verify mismatch.

@@ -77,7 +77,66 @@ def status_counts(status):
     return clean(found), clean(checked)
 
 
+def rnd_cases(g, tmp):
+    """`rnd` (main.c:580-662) pinned to the reference.  Two kinds of fixture:
+    * a range exactly ONE window wide at offset 0 (`-d 0:N`, range = [H + 0, H + 2^N - 1]): every random draw clears /
+      sets to the same bounds, the reference recognises the full range (`is_full`, main.c:643,658) and exits after one
+      window - masks, summary line and found list are all deterministic.  (At an offset > 0 the bits BELOW the window
+      are random too, so no range makes such a run deterministic.)
+    * windows at `-d 128:21` on a 168-bit range: the reference loops for ever, so it is stopped with SIGINT (its handler
+      flushes and exits, main.c:867-872) after a few seconds and the COMPLETE windows are kept: both printed masks,
+      the found lines printed between them and the `found / checked` summary, window by window."""
+    import re
+    sp = os.path.join(tmp, "sparse_rnd.blf")
+    write_blf(sp, synth_bloom_words(12345, seed=7, mode="a|(b&c)"))
+    bloom = {"words": 12345, "seed": 7, "mode": "a|(b&c)"}
+
+    def one_window(name, extra):
+        out = os.path.join(tmp, name + ".txt")
+        if os.path.exists(out):
+            os.unlink(out)
+        args = ["rnd", "-f", sp, "-t", "1"] + extra
+        pr = subprocess.run(["timeout", "120", ref_bin()] + args + ["-q", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        text = pr.stdout.decode()
+        body = text[text.index("[RANDOM MODE]"):].split("\n")
+        summary = re.fullmatch(r"([\d,]+) / ([\d,]+) ~ [\d.]+s", body[4])
+        lines = sorted(l.rstrip("\n") for l in open(out))
+        g["cases"][name] = {"args": args, "bloom": bloom, "header": body[0], "mask_s": body[2], "mask_e": body[3],
+                            "window_found": int(summary.group(1).replace(",", "")), "window_checked": int(summary.group(2).replace(",", "")),
+                            "count": len(lines), "sha256_sorted": digest(lines), "head": lines[:16]}
+        print(f"{name}: {body[2]} .. {body[3]}: {body[4]}")
+
+    one_window("rnd_d0_20_overscan", ["-r", "100000:1fffff", "-d", "0:20"])            # 2^20-key window, 2^21-key job (over-scan)
+    one_window("rnd_d0_22_cu_endo", ["-r", "400000:7fffff", "-d", "0:22", "-a", "cu", "-endo"])  # two jobs, 12 hashes per key
+    # windows at an offset: stop the endless loop after a few seconds, keep the complete windows
+    lo, hi = 1 << 167, (1 << 168) - 1
+    args = ["rnd", "-f", sp, "-t", "1", "-r", f"{lo:x}:{hi:x}", "-d", "128:21"]
+    pr = subprocess.run(["timeout", "-s", "INT", "8", ref_bin()] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    text = pr.stdout.decode()
+    blocks = text[text.index("[RANDOM MODE]"):].split("\n\n")[1:]
+    wins = []
+    for b in blocks:
+        rows = b.split("\n")
+        m = re.fullmatch(r"([\d,]+) / ([\d,]+) ~ [\d.]+s", rows[-1]) if len(rows) >= 3 else None
+        if not m:
+            continue  # the window that was running when the signal arrived
+        found = sorted(rows[2:-1])
+        assert all(re.fullmatch(r"addr33: [0-9a-f]{40} <- [0-9a-f]{64}", f) for f in found), found[:2]
+        wins.append({"mask_s": rows[0], "mask_e": rows[1], "found": int(m.group(1).replace(",", "")), "checked": int(m.group(2).replace(",", "")),
+                     "stdout_lines_sha256": digest(found), "stdout_lines_head": found[:4]})
+        if len(wins) == 4:
+            break
+    assert len(wins) >= 3, text[-2000:]
+    g["cases"]["rnd_windows_d128_21"] = {"args": args, "bloom": bloom, "header": text[text.index("[RANDOM MODE]"):].split("\n")[0], "windows": wins}
+    print(f"rnd_windows_d128_21: {len(wins)} complete windows, found {[w['found'] for w in wins]}")
+
+
 def main():
+    if "--only-rnd" in sys.argv:  # add / refresh the rnd cases without touching the other fixtures
+        g = json.load(open(os.path.join(HERE, "golden.json")))
+        rnd_cases(g, tempfile.mkdtemp())
+        json.dump(g, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+        return
     g = {"reference": "vladkens/ecloop v0.5.0, built by oracle/Makefile `ref`", "cases": {}}
     tmp = tempfile.mkdtemp()
     ones = os.path.join(tmp, "ones.blf")
@@ -149,6 +208,7 @@ def main():
     raw = open(blf_out, "rb").read()
     g["cases"]["blf_gen_puzzles_32768"] = {"bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest(),
                                            "header_hex": raw[:16].hex(), "size_words": struct.unpack("<Q", raw[8:16])[0]}
+    rnd_cases(g, tmp)
     # inputs owned by the reference's data/ directory: stored as data fixtures for the GPU box
     for name in ("btc-puzzles-hash", "btc-bw-hash", "btc-bw-priv"):
         dst = os.path.join(HERE, name)

@@ -29,7 +29,7 @@ class Found(C.Structure):
 
 class AddCfg(C.Structure):
     _fields_ = [("check33", C.c_int), ("check65", C.c_int), ("use_endo", C.c_int), ("ord_offs", C.c_uint32),
-                ("verify", C.c_int), ("threads", C.c_int)]
+                ("verify", C.c_int), ("threads", C.c_int), ("rnd_jobs", C.c_int)]
 
 
 _lib = None
@@ -125,8 +125,9 @@ def digest(lines):
     return hashlib.sha256(("\n".join(sorted(lines)) + "\n").encode()).hexdigest()
 
 
-def add_range(flt, range_s, range_e, a33=True, a65=False, endo=False, offs=0, verify=True, threads=1, cap=1 << 16):
-    cfg = AddCfg(int(a33), int(a65), int(endo), offs, int(verify), threads)
+def add_range(flt, range_s, range_e, a33=True, a65=False, endo=False, offs=0, verify=True, threads=1, cap=1 << 16, rnd=False):
+    """cmd_add over [range_s, range_e); rnd=True: one window of cmd_rnd (full-size jobs, main.c:624)"""
+    cfg = AddCfg(int(a33), int(a65), int(endo), offs, int(verify), threads, int(rnd))
     out = (Found * cap)()
     nout, checked, hashed = C.c_uint64(), C.c_uint64(), C.c_uint64()
     rc = lib().orc_add_range(C.byref(cfg), C.byref(flt.f), fe(range_s), fe(range_e), out, C.c_uint64(cap),

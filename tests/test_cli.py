@@ -202,6 +202,77 @@ def test_rnd_at_configs3_shape_equals_add_on_the_printed_masks(cli, tmp_path, si
     assert "set-ups" in text
 
 
+def rnd_windows(text):
+    """stdout of `rnd` -> header line, [(mask_s line, mask_e line, [found lines printed in the window], found, checked)]"""
+    body = text[text.index("[RANDOM MODE]"):]
+    blocks = body.split("\n\n")
+    wins = []
+    for b in blocks[1:]:
+        rows = [r for r in b.split("\n") if r]
+        if len(rows) < 3 or not re.fullmatch(r"[0-9a-f ]{67}", rows[0]):
+            continue
+        m = re.fullmatch(r"([\d,]+) / ([\d,]+) ~ [\d.]+s", rows[-1])
+        assert m, rows[-1]
+        wins.append((rows[0], rows[1], sorted(rows[2:-1]), int(m.group(1).replace(",", "")), int(m.group(2).replace(",", ""))))
+    return blocks[0], wins
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rnd_d0_20_overscan", "rnd_d0_22_cu_endo"])
+def test_rnd_reproduces_the_references_single_window_runs(cli, tmp_path, name):
+    """the reference's deterministic `rnd` runs (`-d 0:N` on a range one window wide: it recognises the full range and
+    exits after one window, main.c:643,658), captured from the reference binary by tests/golden/make_golden.py:
+    header, both printed masks, the window's `found / checked` summary and the found list must be the reference's."""
+    g = G[name]
+    blf = str(tmp_path / "f.blf")
+    write_blf(blf, synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"]))
+    out = str(tmp_path / "rnd.txt")
+    args = [a for a in g["args"] if a not in ("-t", "1")]
+    args[args.index("-f") + 1] = blf
+    pr = subprocess.run([cli] + args + ["-q", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert pr.returncode == 0, pr.stderr.decode()[-1000:]
+    header, wins = rnd_windows(pr.stdout.decode())
+    assert header == g["header"] and len(wins) == 1
+    ms, me, _, found, checked = wins[0]
+    assert (ms, me) == (g["mask_s"], g["mask_e"]) and (found, checked) == (g["window_found"], g["window_checked"])
+    lines = sorted(l.rstrip("\n") for l in open(out))
+    assert len(lines) == g["count"] and digest(lines) == g["sha256_sorted"] and lines[:16] == g["head"]
+
+
+@pytest.mark.gpu
+def test_rnd_windows_at_an_offset_against_the_oracle(cli, tmp_path):
+    """`rnd -d 128:21` on the 168-bit range of the reference fixture `rnd_windows_d128_21` (same filter): the windows
+    are random, so each one the program prints is checked against the ORACLE's cmd_add workers over the printed bounds
+    (stride 2^128, cmd_rnd's full-size jobs) - the found lines printed between the masks and the summary line - the way
+    tests/test_oracle_golden.py checks the oracle against the windows the reference drew; and the bounds must have the
+    shape gen_random_range gives them (main.c:580-591)."""
+    import orc
+    g = G["rnd_windows_d128_21"]
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    blf = str(tmp_path / "f.blf")
+    write_blf(blf, words)
+    args = [a for a in g["args"] if a not in ("-t", "1")]
+    args[args.index("-f") + 1] = blf
+    lo, hi = (int(x, 16) for x in args[args.index("-r") + 1].split(":"))
+    env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS="3")
+    pr = subprocess.run([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert pr.returncode == 0, pr.stderr.decode()[-1000:]
+    header, wins = rnd_windows(pr.stdout.decode())
+    assert header == g["header"] and len(wins) == 3
+    flt = orc.OrcFilter(bloom_words=words)
+    field = ((1 << 21) - 1) << 128
+    seen = set()
+    for ms, me, printed, found, checked in wins:
+        assert re.fullmatch(r"([0-9a-f]{16} ){3}[0-9a-f]{16}", ms) and re.fullmatch(r"([0-9a-f]{16} ){3}[0-9a-f]{16}", me)
+        s, e = int(ms.replace(" ", ""), 16), int(me.replace(" ", ""), 16)
+        assert lo <= s < e <= hi and s & field == 0 and e == s | field
+        rc, out, n, want_checked, hashed = orc.add_range(flt, s, e, offs=128, rnd=True, threads=8)
+        want = sorted("%s: %s <- %s" % tuple(l.split("\t")) for l in orc.found_lines(out, n))
+        assert rc == 0 and (found, checked) == (n, want_checked) and printed == want and n > 100
+        seen.add(s)
+    assert len(seen) == 3  # three different draws
+
+
 @pytest.mark.gpu
 def test_pause_resume_keys(cli, tmp_path):
     """'p' / 'r' (main.c:874-888, lib/utils.c:559-626): the scan stops at the next status update, the status line offers

@@ -201,6 +201,45 @@ def test_dense_bloom_cu_endo_false_positives():
     run_case("dense_fp_cu_endo", orc.OrcFilter(bloom_words=words), 0x8000, 0x87FF, a65=True, endo=True)
 
 
+def _mask(line):
+    return int(line.replace(" ", ""), 16)
+
+
+@pytest.mark.parametrize("name,kw", [("rnd_d0_20_overscan", {}), ("rnd_d0_22_cu_endo", {"a65": True, "endo": True})])
+def test_rnd_single_window_runs_of_the_reference(name, kw):
+    """`rnd -d 0:N` on a range one window wide: the reference's only deterministic rnd run (is_full, main.c:643,658).
+    The oracle's cmd_add workers with cmd_rnd's full-size jobs (main.c:624) over the printed bounds give the reference's
+    found list and its `found / checked` summary."""
+    g = G[name]
+    s, e = _mask(g["mask_s"]), _mask(g["mask_e"])
+    lo, hi = (int(x, 16) for x in g["args"][g["args"].index("-r") + 1].split(":"))
+    assert (s, e) == (lo, hi) and g["header"].startswith("[RANDOM MODE] offs: 0 ~ bits: ")
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    rc, out, n, checked, hashed = orc.add_range(orc.OrcFilter(bloom_words=words), s, e, rnd=True, threads=8, cap=1 << 16, **kw)
+    lines = sorted(orc.found_lines(out, n))
+    assert rc == 0 and (n, checked) == (g["window_found"], g["window_checked"]) and n == g["count"]
+    assert orc.digest(lines) == g["sha256_sorted"] and lines[:16] == g["head"]
+
+
+def test_rnd_windows_of_the_reference_at_an_offset():
+    """four windows the reference drew at `-d 128:21` on a 168-bit range (stopped by SIGINT): for each, the oracle over
+    the PRINTED bounds with stride 2^128 reproduces the found lines the reference printed between the masks and the
+    window's summary; and the bounds have the shape gen_random_range gives them (main.c:580-591)."""
+    g = G["rnd_windows_d128_21"]
+    lo, hi = (int(x, 16) for x in g["args"][g["args"].index("-r") + 1].split(":"))
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    flt = orc.OrcFilter(bloom_words=words)
+    field = ((1 << 21) - 1) << 128
+    assert g["header"] == "[RANDOM MODE] offs: 128 ~ bits: 21" and len(g["windows"]) >= 3
+    for w in g["windows"]:
+        s, e = _mask(w["mask_s"]), _mask(w["mask_e"])
+        assert lo <= s < e <= hi and s & field == 0 and e == s | field
+        rc, out, n, checked, hashed = orc.add_range(flt, s, e, offs=128, rnd=True, threads=8)
+        assert rc == 0 and (n, checked, hashed) == (w["found"], w["checked"], 1 << 21)
+        printed = sorted("%s: %s <- %s" % tuple(l.split("\t")) for l in orc.found_lines(out, n))  # stdout format, main.c:187-189
+        assert orc.digest(printed) == w["stdout_lines_sha256"] and printed[:4] == w["stdout_lines_head"]
+
+
 def test_mul_flows():
     """`make mul` = 1080 keys; seeded scalar dump through the all-ones bloom."""
     bw = orc.OrcFilter(hashes=[h for h in orc.parse_hash_list(os.path.join(GOLD, "btc-bw-hash")) if h])
