@@ -90,9 +90,16 @@ def parse_hash_list(path):
 
 
 class OrcFilter:
-    def __init__(self, hashes=None, bloom_words=None):
+    def __init__(self, hashes=None, bloom_words=None, borrow=False):
+        """borrow=True: use the caller's uint64 array in place (multi-GB filters: no second copy); it must stay alive"""
         self.f = Filter()
-        if hashes is not None:
+        self._borrowed = None
+        if borrow:
+            w = np.ascontiguousarray(bloom_words, dtype=np.uint64)
+            self._borrowed = w
+            self.f.bits = w.ctypes.data_as(C.POINTER(C.c_uint64))
+            self.f.size = len(w)
+        elif hashes is not None:
             arr = np.ascontiguousarray(np.array(hashes, dtype=np.uint32).reshape(-1, 5))
             lib().orc_filter_from_list(C.byref(self.f), arr.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(len(arr)))
         else:
@@ -107,7 +114,8 @@ class OrcFilter:
 
     def __del__(self):
         try:
-            lib().orc_filter_free(C.byref(self.f))
+            if self._borrowed is None:
+                lib().orc_filter_free(C.byref(self.f))
         except Exception:
             pass
 

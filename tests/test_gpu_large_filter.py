@@ -86,3 +86,37 @@ def test_add_cu_endo_large_filter_matches_oracle(big_words):
                                             endo=True, verify=False, threads=64, cap=1 << 16)
     assert rc == 0 and hashed == nkeys and cnt > 500
     assert lines_of(recs, start) == sorted(orc.found_lines(out, cnt))
+
+
+@pytest.mark.parametrize("nw,label", [(750_000_003, "6.0 GB: configs[2]'s filter size, 32-bit reciprocal modulo"),
+                                      ((1 << 31) + 5, "17.2 GB: >= 2^31 words, the 64-bit branch of bloom_mod")])
+def test_add_against_multi_gigabyte_filters_at_their_real_size(nw, label):
+    """configs[2] at its real filter size, on the driver's box: a synthetic filter of `nw` words (bit density 0.625,
+    generated on the device, one copy kept on the host for the oracle), `add` addr33 over 2^24 keys and `-a cu -endo`
+    over 2^20 keys through k_add at the default geometry; the complete found lists (all false positives, ~1400 and
+    ~1000) equal the oracle's blf_has on the same words.  The 17 GB case is the only place k_add itself takes the
+    64-bit reciprocal modulo (bloom.h: bloom_mod; until round 3 reached through the diag kernel only)."""
+    import torch
+    from ecloop_amd import Device
+    g = torch.Generator(device="cuda:0").manual_seed(nw % 1000003)
+    words = np.empty(nw, dtype=np.uint64)
+    chunk = 1 << 27
+    for at in range(0, nw, chunk):
+        m = min(chunk, nw - at)
+        a, b, c = (torch.randint(-(1 << 63), (1 << 63) - 1, (m,), dtype=torch.int64, device="cuda:0", generator=g) for _ in range(3))
+        words[at : at + m] = (a | (b & c)).cpu().numpy().view(np.uint64)
+    del a, b, c
+    torch.cuda.empty_cache()
+    flt = orc.OrcFilter(bloom_words=words, borrow=True)
+    start = 0x100000000
+    for kw, okw, nkeys in (({}, {}, 1 << 24), ({"a33": True, "a65": True, "endo": True}, {"a65": True, "endo": True}, 1 << 20)):
+        d = Device(0, **kw)
+        try:
+            d.set_bloom(words)
+            recs, n = d.add_range(start, nkeys, cap=1 << 16)
+            assert n == len(recs)
+        finally:
+            d.close()
+        rc, out, cnt, _, hashed = orc.add_range(flt, start, start + nkeys, verify=False, threads=64, cap=1 << 16, **okw)
+        assert rc == 0 and hashed == nkeys and cnt > 500, (label, cnt)
+        assert lines_of(recs, start) == sorted(orc.found_lines(out, cnt)), label
