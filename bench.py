@@ -101,7 +101,7 @@ def cpu_baseline(words):
     filter, same range start, under every compiler flag set that runs here (SURVEY §7 "CPU baseline fairness": the
     reference's own Makefile flags are pathological on some hosts, so one flag set is not a baseline):
       ecloop_sane   -march=x86-64-v2 -msha -mno-avx*   (SHA-NI + scalar RIPEMD)          headline sample: 2^30 keys
-      ecloop_avx2   -march=x86-64-v3 -mno-sha          (portable SHA + AVX2 RIPEMD x8)   2^27 keys
+      ecloop_avx2   -march=x86-64-v3 -mno-sha          (portable SHA + AVX2 RIPEMD x8)   2^29 keys
       ecloop_native -march=native (the reference Makefile's flags, built on the BUILD host's CPU; may not run here)
     value = the best of them; bounded to ~10-40 s of CPU work in all.  Falls back to the oracle port if no binary runs."""
     cores = os.cpu_count() or 1
@@ -134,8 +134,8 @@ def cpu_baseline(words):
     threads = min(cores, 64)
     sets, sample = [], None
     for name, flags, log2n in (("ecloop_sane", "-O3 -ffast-math -march=x86-64-v2 -msha -mno-avx -mno-avx2 -mno-avx512f", 30),
-                               ("ecloop_avx2", "-O3 -ffast-math -march=x86-64-v3 -mno-sha", 27),
-                               ("ecloop_native", "-O3 -ffast-math -march=native (reference Makefile:3-8; native = the build host)", 27)):
+                               ("ecloop_avx2", "-O3 -ffast-math -march=x86-64-v3 -mno-sha", 29),
+                               ("ecloop_native", "-O3 -ffast-math -march=native (reference Makefile:3-8; native = the build host)", 29)):
         binary = os.path.join(ROOT, "oracle", "_ref", name)
         if not os.path.exists(binary):
             sets.append({"binary": name, "flags": flags, "error": "not built (no /root/reference at build time)"})
