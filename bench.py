@@ -599,6 +599,13 @@ def main():
         raise SystemExit(f"[bench] --gpus {args.gpus} contradicts the launcher's WORLD_SIZE {world}")
     local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     _, fake = device_class()
+    if not fake:
+        # torch's HIP runtime (its own copy in the wheel) must come up BEFORE libecloop_hip's (/opt/rocm): the other way
+        # round torch finds "no ROCm-capable device" - and torch is what fills multi-GB synthetic filters on the device
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.cuda.set_device(local)
     if not fake and local == 0:
         from ecloop_amd.build import build_library
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing

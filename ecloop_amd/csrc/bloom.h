@@ -115,7 +115,11 @@ FE_FN bool bloom_mid(const bloom_t& b, const u32 h[5], bool two) {
 // Filters that stay in the 256 MB Infinity Cache take two probes in the middle stage (fewer instructions: 5 % of the
 // candidates reach the loop instead of 14 %); bigger ones take one (every probe is a random HBM sector + TLB miss, and
 // one-at-a-time touches 1.59 sectors per hash instead of 1.79).
+#ifdef ECL_MID_TWO_FORCE /* A/B builds: 0 / 1 fixes the choice whatever the filter size */
+FE_FN bool bloom_mid_two(const bloom_t&) { return ECL_MID_TWO_FORCE != 0; }
+#else
 FE_FN bool bloom_mid_two(const bloom_t& b) { return b.nwords < (1ull << 24); }
+#endif
 FE_FN bool bloom_has(const bloom_t& b, const u32 h[5]) { return bloom_stage1(b, h) && bloom_stage2(b, h); }
 #if defined(__HIPCC__)
 // lib/utils.c:290-306 (blf_add) for one hash: 20 atomic ORs
