@@ -152,7 +152,30 @@ def analyse(path=ASM, kernel=K_ADD33):
             res["fingerprint"] = {"kernel_valu": total["valu"], "which_loop_valu": excl[W]["valu"], "which_loop_mad64": excl[W]["mad64"],
                                   "which_loop_fast": excl[W]["fast"], "table_loop_valu": excl[T]["valu"],
                                   "prefix_loop_valu": res.get("prefix_loop", zero())["valu"], "scratch_instr": total["scratch"]}
+            try:
+                sp = spills(path).get(kernel)
+                if sp:
+                    res["fingerprint"]["vgpr_spill_count"] = sp["vgpr_spill_count"]
+                    res["fingerprint"]["scratch_bytes"] = sp["scratch_bytes"]
+            except Exception:
+                pass
     return res
+
+
+def spills(path=ASM, prefix="_Z5k_add"):
+    """vgpr_spill_count / private_segment_fixed_size / vgpr_count of every instantiation of the add kernel, from the code
+    object's metadata (DESIGN.md states these numbers; tests/test_profiles_fresh.py compares)"""
+    s = open(path).read()
+    out = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\n(?=  - \.agpr_count:|amdhsa\.target|\.\.\.)", s, re.S):
+        blk = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name or not name.group(1).startswith(prefix):
+            continue
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+        out[name.group(1)] = {"vgpr_count": g("vgpr_count"), "vgpr_spill_count": g("vgpr_spill_count"),
+                              "scratch_bytes": g("private_segment_fixed_size")}
+    return out
 
 
 def main():
@@ -173,6 +196,8 @@ def main():
     if "per_key_static" in a:
         print("per key (static, upper estimate): %s" % {k: round(v, 1) for k, v in a["per_key_static"].items()})
         print("fingerprint: %s" % a["fingerprint"])
+    for k, v in sorted(spills(path).items()):
+        print("  %s: %s" % (k, v))
 
 
 if __name__ == "__main__":
