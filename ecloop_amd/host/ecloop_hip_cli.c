@@ -2,14 +2,17 @@
  * ecloop-hip — host program with ecloop's command-line surface (add / mul / rnd, blf-gen / blf-check,
  * -f -o -t -a -r -d -q -endo -seed -raw), driving MI355X GPUs through the C ABI of include/ecloop_hip.h.
  *
- * Plain C, links only libecloop_hip.so.  Everything here is what the reference keeps on the host side of the
- * boundary (citations into /root/reference): filter loading (main.c:71-131), range / offset
- * parsing (main.c:666-746), the job arithmetic of cmd_add (main.c:405-454), calc_priv (main.c:267-276),
- * the pk_verify_hash self-check (main.c:248-263, done by re-deriving the hit on the device with the independent
- * double-and-add kernel), the found sink and status line formats (main.c:134-203), cmd_mul's line reader
- * (main.c:542-576), cmd_rnd's window generator (main.c:580-662), blf-gen / blf-check (utils.c:400-529).
- * `-t N` selects the number of GPUs (one host thread per device; default: all): the scan is range-partitioned,
- * no collective.  All curve and hash work for the search itself happens on the device.
+ * Plain C, links only libecloop_hip.so.  What lives here is what the reference keeps on the host side of the
+ * boundary (citations into /root/reference): reading the filter (main.c:71-131), range / window
+ * arguments (main.c:666-746), the job arithmetic of cmd_add (main.c:405-454), calc_priv (main.c:267-276), the
+ * pk_verify_hash check of every hit (main.c:248-263; here one batched device call per scan chunk, ecl_hip_verify),
+ * the found sink and the status line (main.c:134-203), cmd_mul's line reader (main.c:542-576), cmd_rnd's window
+ * generator (main.c:580-662), blf-gen / blf-check (utils.c:400-529).  The program is organised around four objects of
+ * its own - opts_t (the command line, parsed once), filter_t (bloom words + optional sorted list), report_t (found
+ * sink, status line, pause state) and scan_t (one contiguous run of keys handed out to the device threads in chunks) -
+ * not around the reference's ctx_t; formats, messages and counters are the reference's, byte for byte.
+ * `-t N` selects the number of GPUs (one host thread per device context; default: all): a scan is range-partitioned,
+ * no collective.  All curve and hash work of the search happens on the device; there is no CPU fallback.
  */
 #define _GNU_SOURCE
 #include <ctype.h>
@@ -18,15 +21,16 @@
 #include <pthread.h>
 #include <signal.h>
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <fcntl.h>
 #include <sys/mman.h>
-#include <sys/select.h>
+#include <poll.h>
 #include <sys/stat.h>
-#include <sys/time.h>
+#include <time.h>
 #include <termios.h>
 #include <unistd.h>
 
@@ -133,230 +137,310 @@ static sc calc_priv(sc start, sc stride, u64 off, int endo) {
 }
 
 /* ------------------------------------------------------------------------------------------- small utilities */
-static u64 tsnow(void) {
-  struct timeval tv;
-  gettimeofday(&tv, NULL);
-  return (u64)tv.tv_sec * 1000 + tv.tv_usec / 1000;
+static u64 ms_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (u64)ts.tv_sec * 1000 + (u64)ts.tv_nsec / 1000000;
 }
-typedef struct { int argc; const char **argv; } args_t;
-static bool args_bool(args_t *a, const char *name) {
-  for (int i = 1; i < a->argc; ++i)
-    if (strcmp(a->argv[i], name) == 0) return true;
-  return false;
+static u64 us_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (u64)ts.tv_sec * 1000000 + (u64)ts.tv_nsec / 1000;
 }
-static const char *arg_str(args_t *a, const char *name) {
-  for (int i = 1; i < a->argc - 1; ++i)
-    if (strcmp(a->argv[i], name) == 0) return a->argv[i + 1];
+static void erase_status_line(void) { fputs("\033[2K\r", stderr); }
+
+/* ------------------------------------------------------------------------------------------- command line */
+/* Every option of every command, parsed in ONE pass over argv into this struct: a flag that takes a value consumes the
+   next argument, anything else is left alone (`blf-check` reads hashes from the bare words).  Spelling and meaning of
+   the reference's flags (main.c:794-862, utils.c:157-185), plus -bin / -host and the switches of the hidden test
+   commands (plan: -rnd -mul -visible). */
+typedef struct {
+  const char *filter, *outfile, *range, *window, *seed, *addr, *gpus, *count, *visible;
+  bool quiet, endo, raw, bin, version, host_only, rnd_jobs, as_mul;
+} opts_t;
+typedef struct { const char *flag; size_t at; bool takes_value; } optdef_t;
+static const optdef_t OPTDEFS[] = {
+    {"-f", offsetof(opts_t, filter), true},       {"-o", offsetof(opts_t, outfile), true},  {"-r", offsetof(opts_t, range), true},
+    {"-d", offsetof(opts_t, window), true},       {"-seed", offsetof(opts_t, seed), true},  {"-a", offsetof(opts_t, addr), true},
+    {"-t", offsetof(opts_t, gpus), true},         {"-n", offsetof(opts_t, count), true},    {"-visible", offsetof(opts_t, visible), true},
+    {"-q", offsetof(opts_t, quiet), false},       {"-endo", offsetof(opts_t, endo), false}, {"-raw", offsetof(opts_t, raw), false},
+    {"-bin", offsetof(opts_t, bin), false},       {"-v", offsetof(opts_t, version), false}, {"-host", offsetof(opts_t, host_only), false},
+    {"-rnd", offsetof(opts_t, rnd_jobs), false},  {"-mul", offsetof(opts_t, as_mul), false},
+};
+static void opts_parse(opts_t *o, int argc, const char **argv) {
+  memset(o, 0, sizeof *o);
+  for (int i = 1; i < argc; ++i)
+    for (size_t d = 0; d < sizeof OPTDEFS / sizeof OPTDEFS[0]; ++d) {
+      if (strcmp(argv[i], OPTDEFS[d].flag) != 0) continue;
+      char *field = (char *)o + OPTDEFS[d].at;
+      if (!OPTDEFS[d].takes_value) *(bool *)field = true;
+      else if (i + 1 < argc && !*(const char **)field) *(const char **)field = argv[++i];
+      break;
+    }
+}
+static u64 opt_number(const char *text, u64 fallback) { return text ? strtoull(text, NULL, 10) : fallback; }
+
+/* ------------------------------------------------------------------------------------------- filter (host side) */
+/* What -f names: the bloom words the GPUs probe, and - when the file was a hash list - the sorted list that confirms a
+   bloom hit exactly (ctx->blf + ctx->to_find_hashes, main.c:48-51).  `.blf` files carry the words only. */
+#define BLF_MAGIC 0x45434246u /* utils.c:274-275: 'ECBF', version 1, u64 word count, words */
+#define BLF_VERSION 1u
+typedef struct {
+  u64 *words, nwords;
+  u32 *list; /* nlist x 5 words, ascending, unique; NULL = bloom-only mode */
+  u64 nlist;
+} filter_t;
+
+/* the 20 bit positions of a hash160 (utils.c:290-306): five overlapping 64-bit words, shifted by 24 / 28 / 36 / 40 */
+static void bloom_positions(u64 pos[20], const u32 h[5]) {
+  u64 a[6];
+  for (int j = 0; j < 5; ++j) a[j] = (u64)h[(2 * j) % 5] << 32 | h[(2 * j + 1) % 5];
+  a[5] = a[0];
+  static const int SHIFT[4] = {24, 28, 36, 40};
+  for (int p = 0; p < 20; ++p) pos[p] = a[p % 5] << SHIFT[p / 5] | a[p % 5 + 1] >> SHIFT[p / 5];
+}
+static void bloom_set(filter_t *f, const u32 h[5]) {
+  u64 pos[20];
+  bloom_positions(pos, h);
+  for (int p = 0; p < 20; ++p) f->words[(pos[p] >> 6) % f->nwords] |= 1ULL << (pos[p] & 63);
+}
+static bool bloom_test(const filter_t *f, const u32 h[5]) {
+  u64 pos[20];
+  bloom_positions(pos, h);
+  int p = 0;
+  while (p < 20 && ((f->words[(pos[p] >> 6) % f->nwords] >> (pos[p] & 63)) & 1)) ++p;
+  return p == 20;
+}
+static bool blf_write(const char *path, const filter_t *f) { /* utils.c:328-360 */
+  FILE *out = fopen(path, "wb");
+  if (!out) return false;
+  struct { u32 magic, version; u64 nwords; } head = {BLF_MAGIC, BLF_VERSION, f->nwords};
+  bool ok = fwrite(&head, sizeof head, 1, out) == 1 && fwrite(f->words, 8, f->nwords, out) == f->nwords;
+  return fclose(out) == 0 && ok;
+}
+/* utils.c:362-396; NULL on success, else the reference's message for what went wrong */
+static const char *blf_read(const char *path, filter_t *f) {
+  FILE *in = fopen(path, "rb");
+  if (!in) return "failed to open input file";
+  struct { u32 magic, version; u64 nwords; } head;
+  const char *why = NULL;
+  u64 *words = NULL;
+  if (fread(&head, sizeof head, 1, in) != 1) why = "failed to read bloom filter header";
+  else if (head.magic != BLF_MAGIC || head.version != BLF_VERSION) why = "invalid bloom filter version; create a new filter with blf-gen command";
+  else {
+    words = calloc(head.nwords ? head.nwords : 1, 8);
+    if (!words || fread(words, 8, head.nwords, in) != head.nwords) why = "failed to read bloom filter bits";
+  }
+  fclose(in);
+  if (why) { free(words); return why; }
+  f->words = words, f->nwords = head.nwords;
   return NULL;
 }
-static u64 args_uint(args_t *a, const char *name, u64 def) {
-  const char *s = arg_str(a, name);
-  return s ? strtoull(s, NULL, 10) : def;
-}
-static void term_clear_line(void) { fputs("\033[2K\r", stderr); }
-
-/* ------------------------------------------------------------------------------------------- bloom filter (host) */
-#define BLF_MAGIC 0x45434246u
-#define BLF_VERSION 1u
-typedef struct { u64 size; u64 *bits; } blf_t;
-
-static void blf_indices(u64 idx[20], const u32 h[5]) { /* utils.c:290-306 */
-  u64 a[6] = {(u64)h[0] << 32 | h[1], (u64)h[2] << 32 | h[3], (u64)h[4] << 32 | h[0], (u64)h[1] << 32 | h[2],
-              (u64)h[3] << 32 | h[4], 0};
-  a[5] = a[0];
-  static const int S[4] = {24, 28, 36, 40};
-  for (int s = 0; s < 4; ++s)
-    for (int j = 0; j < 5; ++j) idx[s * 5 + j] = a[j] << S[s] | a[j + 1] >> S[s];
-}
-static void blf_add(blf_t *b, const u32 h[5]) {
-  u64 idx[20];
-  blf_indices(idx, h);
-  for (int i = 0; i < 20; ++i) b->bits[(idx[i] >> 6) % b->size] |= 1ULL << (idx[i] & 63);
-}
-static bool blf_has(const blf_t *b, const u32 h[5]) {
-  u64 idx[20];
-  blf_indices(idx, h);
-  for (int i = 0; i < 20; ++i)
-    if (!((b->bits[(idx[i] >> 6) % b->size] >> (idx[i] & 63)) & 1)) return false;
-  return true;
-}
-static bool blf_save(const char *path, const blf_t *b) { /* utils.c:328-360 */
-  FILE *f = fopen(path, "wb");
-  if (!f) return false;
-  u32 head[2] = {BLF_MAGIC, BLF_VERSION};
-  bool ok = fwrite(head, 4, 2, f) == 2 && fwrite(&b->size, 8, 1, f) == 1 && fwrite(b->bits, 8, b->size, f) == b->size;
-  fclose(f);
-  return ok;
-}
-static bool blf_load(const char *path, blf_t *b) { /* utils.c:362-396 */
-  FILE *f = fopen(path, "rb");
-  if (!f) { fprintf(stderr, "failed to open input file\n"); return false; }
-  u32 head[2];
-  u64 size;
-  if (fread(head, 4, 2, f) != 2 || fread(&size, 8, 1, f) != 1) {
-    fprintf(stderr, "failed to read bloom filter header\n");
-    fclose(f);
-    return false;
-  }
-  if (head[0] != BLF_MAGIC || head[1] != BLF_VERSION) {
-    fprintf(stderr, "invalid bloom filter version; create a new filter with blf-gen command\n");
-    fclose(f);
-    return false;
-  }
-  u64 *bits = calloc(size ? size : 1, 8);
-  if (fread(bits, 8, size, f) != size) {
-    fprintf(stderr, "failed to read bloom filter bits\n");
-    fclose(f);
-    free(bits);
-    return false;
-  }
-  fclose(f);
-  b->size = size, b->bits = bits;
-  return true;
-}
-static int cmp160(const void *a, const void *b) { /* addr.c:18-26 */
+static int order160(const void *a, const void *b) { /* compare_160, addr.c:18-26: word by word */
   const u32 *x = a, *y = b;
-  for (int i = 0; i < 5; ++i)
-    if (x[i] != y[i]) return x[i] < y[i] ? -1 : 1;
-  return 0;
+  int i = 0;
+  while (i < 4 && x[i] == y[i]) ++i;
+  return (x[i] > y[i]) - (x[i] < y[i]);
 }
-static bool parse_hash40(const char *s, u32 h[5]) {
-  for (int i = 0; i < 40; ++i)
-    if (!isxdigit((unsigned char)s[i])) return false;
-  for (int j = 0; j < 5; ++j) {
-    char t[9];
-    memcpy(t, s + j * 8, 8), t[8] = 0;
-    h[j] = (u32)strtoul(t, NULL, 16);
+/* 40 hex digits -> 5 words; false if any character is not a hex digit */
+static bool hash160_from_hex(const char *s, u32 h[5]) {
+  for (int w = 0; w < 5; ++w) {
+    u32 v = 0;
+    for (int d = 0; d < 8; ++d) {
+      int c = (unsigned char)s[w * 8 + d], x = c >= '0' && c <= '9' ? c - '0' : (c | 32) >= 'a' && (c | 32) <= 'f' ? (c | 32) - 'a' + 10 : -1;
+      if (x < 0) return false;
+      v = v << 4 | (u32)x;
+    }
+    h[w] = v;
   }
   return true;
 }
-
-/* ------------------------------------------------------------------------------------------- context */
-enum { CMD_NIL, CMD_ADD, CMD_MUL, CMD_RND };
-typedef struct ctx_t {
-  int cmd;
-  pthread_mutex_t lock;
-  int ngpus;
-  ecl_hip *dev[MAX_GPUS];
-  u64 k_checked, k_found;
-  bool a33, a65, endo, quiet, use_color, raw_text, bin_input, parse_only, plan_only, has_seed, finished;
-  FILE *outfile;
-  u64 ts_started, ts_updated, ts_printed;
-  volatile bool paused; /* 'p' / 'r' on the terminal (main.c:41-46,874-888) */
-  u64 ts_paused_at, paused_time;
-  u32 *list; /* sorted unique hashes (5 words each) or NULL in bloom-only mode (main.c:49-51) */
-  u64 list_count;
-  blf_t blf;
-  sc range_s, range_e, stride_k;
-  u32 ord_offs, ord_size;
-} ctx_t;
-
-static void die_ecl(ctx_t *ctx, int g, int rc, const char *what) {
-  fprintf(stderr, "\n[!] %s: %s (%s)\n", what, ecl_hip_strerror(rc), ctx->dev[g] ? ecl_hip_last_error(ctx->dev[g]) : "");
-  exit(1);
+/* Entries of a hash list, as the reference's reader sees them (main.c:96-110: fgets into a 41-byte buffer consumes a line
+   in pieces of 40 characters, and every FULL piece is an entry).  Stated on the file image: cut at '\n', walk each line
+   in steps of 40, keep the pieces that are 40 clean hex digits (the reference parses garbage out of the others - one
+   phantom entry for the comment line of data/btc-bw-hash; dropped here).  out == NULL: count only. */
+static size_t hashlist_entries(const char *text, size_t len, u32 *out) {
+  size_t n = 0;
+  for (size_t at = 0; at < len;) {
+    const char *nl = memchr(text + at, '\n', len - at);
+    size_t eol = nl ? (size_t)(nl - text) : len;
+    for (size_t p = at; p + 40 <= eol; p += 40) {
+      u32 h[5];
+      if (!hash160_from_hex(text + p, h)) continue;
+      if (out) memcpy(out + n * 5, h, 20);
+      n++;
+    }
+    at = eol + 1;
+  }
+  return n;
 }
-
-/* load_filter (main.c:71-131).  fgets into a 41-byte buffer reads 40-character chunks; only full chunks count.
-   Chunks that are not clean hex are dropped (the reference parses garbage out of them). */
-static void load_filter(ctx_t *ctx, const char *path) {
+static char *slurp(FILE *in, size_t *len) {
+  size_t cap = 1 << 16, n = 0, got;
+  char *buf = malloc(cap);
+  while ((got = fread(buf + n, 1, cap - n, in)) > 0)
+    if ((n += got) == cap) buf = realloc(buf, cap *= 2);
+  *len = n;
+  return buf;
+}
+/* -f <file> (load_filter, main.c:71-131): `.blf` -> bloom-only mode; anything else -> hash list, sorted, duplicates
+   removed, plus an in-memory bloom of two words per entry.  Errors end the program with the reference's messages. */
+static void filter_open(filter_t *f, const char *path) {
+  memset(f, 0, sizeof *f);
   if (!path) { fprintf(stderr, "missing filter file\n"); exit(1); }
-  FILE *f = fopen(path, "rb");
-  if (!f) { fprintf(stderr, "failed to open filter file: %s\n", path); exit(1); }
-  const char *ext = strrchr(path, '.');
-  if (ext && strcmp(ext, ".blf") == 0) {
-    fclose(f);
-    if (!blf_load(path, &ctx->blf)) exit(1);
+  FILE *in = fopen(path, "rb");
+  if (!in) { fprintf(stderr, "failed to open filter file: %s\n", path); exit(1); }
+  const char *dot = strrchr(path, '.');
+  if (dot && !strcmp(dot, ".blf")) {
+    fclose(in);
+    const char *why = blf_read(path, f);
+    if (why) { fprintf(stderr, "%s\n", why); exit(1); }
     return;
   }
-  size_t cap = 32, n = 0;
-  u32 *hs = malloc(cap * 20);
-  char line[41];
-  while (fgets(line, sizeof line, f)) {
-    if (strlen(line) != 40) continue;
-    if (n >= cap) cap *= 2, hs = realloc(hs, cap * 20);
-    if (parse_hash40(line, hs + n * 5)) n++;
-  }
-  fclose(f);
-  if (n == 0) { fprintf(stderr, "no hashes in filter file\n"); exit(1); }
-  qsort(hs, n, 20, cmp160);
-  size_t u = 0;
+  size_t len;
+  char *text = slurp(in, &len);
+  fclose(in);
+  size_t n = hashlist_entries(text, len, NULL);
+  if (!n) { fprintf(stderr, "no hashes in filter file\n"); exit(1); }
+  u32 *hs = malloc(n * 20);
+  hashlist_entries(text, len, hs);
+  free(text);
+  qsort(hs, n, 20, order160);
+  size_t kept = 1;
   for (size_t i = 1; i < n; ++i)
-    if (memcmp(hs + u * 5, hs + i * 5, 20) != 0) memcpy(hs + (++u) * 5, hs + i * 5, 20);
-  ctx->list = hs, ctx->list_count = u + 1;
-  ctx->blf.size = ctx->list_count * 2;
-  ctx->blf.bits = calloc(ctx->blf.size, 8);
-  for (size_t i = 0; i < ctx->list_count; ++i) blf_add(&ctx->blf, hs + i * 5);
+    if (order160(hs + (kept - 1) * 5, hs + i * 5)) memmove(hs + kept++ * 5, hs + i * 5, 20);
+  f->list = hs, f->nlist = kept;
+  f->nwords = 2 * kept, f->words = calloc(f->nwords, 8);
+  for (size_t i = 0; i < kept; ++i) bloom_set(f, hs + i * 5);
+}
+/* second stage of ctx_check_hash (main.c:212-216): the device reports bloom hits, the list decides */
+static bool filter_confirms(const filter_t *f, const u32 h[5]) {
+  return !f->list || bsearch(h, f->list, f->nlist, 20, order160) != NULL;
 }
 
-/* status line, main.c:134-144 */
-static void ctx_print_unlocked(ctx_t *ctx) {
-  const char *msg = ctx->finished ? "" : (ctx->paused ? " ('r' \xe2\x80\x93 resume)" : " ('p' \xe2\x80\x93 pause)");
-  int64_t eff = (int64_t)(ctx->ts_updated - ctx->ts_started) - (int64_t)ctx->paused_time;
-  double dt = (eff < 1 ? 1 : eff) / 1000.0;
-  double it = ctx->k_checked / dt / 1000000;
-  term_clear_line();
-  fprintf(stderr, "%.2fs ~ %.2f Mkeys/s ~ %'llu / %'llu%s%c", dt, it, (unsigned long long)ctx->k_found,
-          (unsigned long long)ctx->k_checked, msg, ctx->finished ? '\n' : '\r');
+/* ------------------------------------------------------------------------------------------- found sink + status line */
+/* One object for everything the program reports while it runs: found keys (stdout unless -q, the -o file), the two
+   counters behind the status line, the clock with the paused time taken out.  Formats are the reference's
+   (ctx_write_found main.c:182-203, ctx_print_status main.c:134-144, ctx_update main.c:158-172), byte for byte; the device
+   threads and the key listener share it through its mutex. */
+typedef struct {
+  pthread_mutex_t mu;
+  FILE *file;      /* -o (appended to), or NULL */
+  bool quiet;      /* -q: nothing on stdout */
+  u64 found, checked;
+  u64 t_start, t_progress, t_shown; /* ms: clock start, last progress report, last status print */
+  u64 paused_ms, paused_since;
+  volatile bool paused; /* read by the device threads without the mutex, like the reference's flag (main.c:153) */
+  bool closed;
+} report_t;
+
+static void hex_of_words(char *dst, const u32 *w, int n) { /* 8 digits per word, most significant word first as given */
+  for (int i = 0; i < n; ++i) sprintf(dst + 8 * i, "%08x", w[i]);
+}
+static void hex_of_scalar(char dst[65], const sc *k) {
+  for (int i = 0; i < 4; ++i) sprintf(dst + 16 * i, "%016llx", (unsigned long long)k->w[3 - i]);
+}
+static void report_init(report_t *r, const char *outfile, bool quiet) {
+  memset(r, 0, sizeof *r);
+  pthread_mutex_init(&r->mu, NULL);
+  r->quiet = quiet;
+  if (outfile) r->file = fopen(outfile, "a");
+  r->t_start = r->t_progress = ms_now();
+  r->t_shown = r->t_start - 5000;
+}
+static void report_restart_clock(report_t *r) { r->t_start = ms_now(); } /* the commands start their clock after bring-up */
+/* "<secs>s ~ <rate> Mkeys/s ~ <found> / <checked>" + the key hint; '\r' while running, '\n' once closed */
+static void status_show_locked(report_t *r) {
+  int64_t run_ms = (int64_t)(r->t_progress - r->t_start) - (int64_t)r->paused_ms;
+  double secs = (run_ms < 1 ? 1 : run_ms) / 1000.0;
+  const char *hint = r->closed ? "" : r->paused ? " ('r' \xe2\x80\x93 resume)" : " ('p' \xe2\x80\x93 pause)";
+  erase_status_line();
+  fprintf(stderr, "%.2fs ~ %.2f Mkeys/s ~ %'llu / %'llu%s%c", secs, r->checked / secs / 1000000, (unsigned long long)r->found,
+          (unsigned long long)r->checked, hint, r->closed ? '\n' : '\r');
   fflush(stderr);
 }
-static void ctx_update(ctx_t *ctx, u64 k) { /* main.c:158-172 */
-  u64 ts = tsnow();
-  pthread_mutex_lock(&ctx->lock);
-  ctx->k_checked += k, ctx->ts_updated = ts;
-  if (ts - ctx->ts_printed >= 100) ctx->ts_printed = ts, ctx_print_unlocked(ctx);
-  pthread_mutex_unlock(&ctx->lock);
-  while (ctx->paused) usleep(100000); /* ctx_check_paused, main.c:152-156: the caller holds no device work here */
-}
-static void ctx_finish(ctx_t *ctx) { /* main.c:174-180 */
-  pthread_mutex_lock(&ctx->lock);
-  ctx->finished = true, ctx->ts_updated = tsnow();
-  ctx_print_unlocked(ctx);
-  if (ctx->outfile) fclose(ctx->outfile);
-  pthread_mutex_unlock(&ctx->lock);
-}
-/* ctx_write_found, main.c:182-203 */
-static void ctx_write_found(ctx_t *ctx, const char *label, const u32 h[5], sc pk) {
-  pthread_mutex_lock(&ctx->lock);
-  if (!ctx->quiet) {
-    term_clear_line();
-    printf("%s: %08x%08x%08x%08x%08x <- %016llx%016llx%016llx%016llx\n", label, h[0], h[1], h[2], h[3], h[4],
-           (unsigned long long)pk.w[3], (unsigned long long)pk.w[2], (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
-    fflush(stdout);
+/* one found key: "addr33: <hash160> <- <key>" on stdout, "addr33\t<hash160>\t<key>" in the file; counts it */
+static void report_hit(report_t *r, bool compressed, const u32 h160[5], const sc *key) {
+  char hh[41], kk[65];
+  hex_of_words(hh, h160, 5);
+  hex_of_scalar(kk, key);
+  const char *label = compressed ? "addr33" : "addr65";
+  const struct { FILE *to; const char *fmt; } dest[2] = {{r->quiet ? NULL : stdout, "%s: %s <- %s\n"}, {r->file, "%s\t%s\t%s\n"}};
+  pthread_mutex_lock(&r->mu);
+  for (int d = 0; d < 2; ++d) {
+    if (!dest[d].to) continue;
+    if (dest[d].to == stdout) erase_status_line();
+    fprintf(dest[d].to, dest[d].fmt, label, hh, kk);
+    fflush(dest[d].to);
   }
-  if (ctx->outfile) {
-    fprintf(ctx->outfile, "%s\t%08x%08x%08x%08x%08x\t%016llx%016llx%016llx%016llx\n", label, h[0], h[1], h[2], h[3], h[4],
-            (unsigned long long)pk.w[3], (unsigned long long)pk.w[2], (unsigned long long)pk.w[1], (unsigned long long)pk.w[0]);
-    fflush(ctx->outfile);
+  r->found++;
+  status_show_locked(r);
+  pthread_mutex_unlock(&r->mu);
+}
+/* `units` more keys checked (status units: the reference counts job_size per job, x6 with -endo, main.c:431); the line
+   is redrawn at most every 100 ms; a paused run parks the caller here, between two device calls */
+static void report_progress(report_t *r, u64 units) {
+  u64 now = ms_now();
+  pthread_mutex_lock(&r->mu);
+  r->checked += units, r->t_progress = now;
+  if (now - r->t_shown >= 100) r->t_shown = now, status_show_locked(r);
+  pthread_mutex_unlock(&r->mu);
+  while (r->paused) usleep(100000);
+}
+static void report_pause(report_t *r, bool on) { /* 'p' / 'r' (main.c:874-888): paused time does not count */
+  pthread_mutex_lock(&r->mu);
+  if (on != r->paused) {
+    u64 now = ms_now();
+    if (on) r->paused_since = now;
+    else r->paused_ms += now - r->paused_since;
+    r->paused = on;
+    status_show_locked(r);
   }
-  ctx->k_found += 1;
-  ctx_print_unlocked(ctx);
-  pthread_mutex_unlock(&ctx->lock);
+  pthread_mutex_unlock(&r->mu);
 }
-/* second stage of ctx_check_hash (main.c:212-216) */
-static bool list_confirm(const ctx_t *ctx, const u32 h[5]) {
-  return !ctx->list || bsearch(h, ctx->list, ctx->list_count, 20, cmp160) != NULL;
+static void report_close(report_t *r) { /* ctx_finish, main.c:174-180 */
+  pthread_mutex_lock(&r->mu);
+  r->closed = true, r->t_progress = ms_now();
+  status_show_locked(r);
+  if (r->file) fclose(r->file), r->file = NULL;
+  pthread_mutex_unlock(&r->mu);
 }
-/* pk_verify_hash (main.c:248-263) for all hits of one device call: re-derive them from their scalars on the device in
-   one batch, on a path that shares no kernel with the walk (ecl_hip_verify: window-table sum, own inversion per key) */
-static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *hits, u32 n) {
+
+/* ------------------------------------------------------------------------------------------- one run of a search command */
+enum { CMD_NIL, CMD_ADD, CMD_MUL, CMD_RND };
+typedef struct run_t {
+  int cmd;
+  opts_t opt;
+  filter_t flt;
+  report_t rep;
+  int ngpus; /* device contexts (threads); `mul` opens two per GPU */
+  ecl_hip *dev[MAX_GPUS];
+  bool a33, a65, endo, colour, bin, parse_only, seeded;
+  sc range_s, range_e, stride_k;
+  u32 ord_offs, ord_size;
+} run_t;
+
+static void die_ecl(run_t *run, int g, int rc, const char *what) {
+  fprintf(stderr, "\n[!] %s: %s (%s)\n", what, ecl_hip_strerror(rc), run->dev[g] ? ecl_hip_last_error(run->dev[g]) : "");
+  exit(1);
+}
+/* pk_verify_hash (main.c:248-263) for all hits of one device call at once: both hash160 values of every reported key are
+   derived again on the device by the window-table sum (ecl_hip_verify: not the walk kernel; own inversion per key) and
+   compared with what the walk reported; a mismatch is fatal, with the reference's diagnostics */
+static void verify_hits(run_t *run, int g, const sc *keys, const ecl_found *hits, u32 n) {
   if (!n) return;
-  u64 (*k)[4] = malloc((size_t)n * 32);
   u32 (*h33)[5] = malloc((size_t)n * 20), (*h65)[5] = malloc((size_t)n * 20);
-  u8 *ok = malloc(n);
-  for (u32 i = 0; i < n; ++i) memcpy(k[i], pks[i].w, 32);
-  int rc = ecl_hip_verify(ctx->dev[g], k, n, h33, h65, ok);
-  if (rc != ECL_OK) die_ecl(ctx, g, rc, "verify");
+  u8 *finite = malloc(n);
+  int rc = ecl_hip_verify(run->dev[g], (const uint64_t(*)[4])keys, n, h33, h65, finite);
+  if (rc != ECL_OK) die_ecl(run, g, rc, "verify");
   for (u32 i = 0; i < n; ++i) {
-    const u32 *r = hits[i].compressed ? h33[i] : h65[i], *h = hits[i].h160;
-    if (ok[i] && memcmp(r, h, 20) == 0) continue;
-    fprintf(stderr, "[!] error: hash mismatch (compressed: %d endo: %d)\n", hits[i].compressed, hits[i].endo);
-    fprintf(stderr, "pk: %016llx%016llx%016llx%016llx\n", (unsigned long long)pks[i].w[3], (unsigned long long)pks[i].w[2],
-            (unsigned long long)pks[i].w[1], (unsigned long long)pks[i].w[0]);
-    fprintf(stderr, "lh: %08x%08x%08x%08x%08x\n", h[0], h[1], h[2], h[3], h[4]);
-    fprintf(stderr, "rh: %08x%08x%08x%08x%08x\n", r[0], r[1], r[2], r[3], r[4]);
+    const u32 *want = hits[i].compressed ? h33[i] : h65[i];
+    if (finite[i] && !memcmp(want, hits[i].h160, 20)) continue;
+    char kk[65], lh[41], rh[41];
+    hex_of_scalar(kk, &keys[i]), hex_of_words(lh, hits[i].h160, 5), hex_of_words(rh, want, 5);
+    fprintf(stderr, "[!] error: hash mismatch (compressed: %d endo: %d)\npk: %s\nlh: %s\nrh: %s\n", hits[i].compressed, hits[i].endo, kk, lh, rh);
     exit(1);
   }
-  free(k), free(h33), free(h65), free(ok);
+  free(h33), free(h65), free(finite);
 }
 
 /* ------------------------------------------------------------------------------------------- add */
@@ -365,7 +449,7 @@ static void pk_verify_hashes(ctx_t *ctx, int g, const sc *pks, const ecl_found *
    (main.c:418-431): a GPU that sustains a few percent more clock simply takes more chunks, and a scan of any length
    (the default range 0x800:p included) streams through without its key count having to fit 64 bits. */
 typedef struct {
-  ctx_t *ctx;
+  run_t *run;
   sc rs;             /* first scalar */
   sc hashed;         /* keys to hash (256-bit: `add` without -r walks ~2^256 / stride keys) */
   sc next;           /* keys handed out so far */
@@ -383,15 +467,15 @@ static sc sc_add_u64_raw(sc a, u64 v) {
   return r;
 }
 /* scalar of key number `off` (256-bit count): rs + off * stride (mod n); stride is a power of two */
-static sc scan_scalar(const ctx_t *ctx, const sc *rs, const sc *off) {
+static sc scan_scalar(const run_t *run, const sc *rs, const sc *off) {
   sc o = sc_reduce(*off); /* off < 2^256 < 2n */
-  return sc_add(sc_reduce(*rs), sc_mul(ctx->stride_k, o));
+  return sc_add(sc_reduce(*rs), sc_mul(run->stride_k, o));
 }
 
 static void *scan_worker(void *arg) {
   scan_worker_t *w = arg;
   scan_t *sn = w->scan;
-  ctx_t *ctx = sn->ctx;
+  run_t *run = sn->run;
   u32 cap = 4096;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
   for (;;) {
@@ -414,26 +498,26 @@ static void *scan_worker(void *arg) {
     sn->status_given += st;
     pthread_mutex_unlock(&sn->mu);
 
-    sc s = scan_scalar(ctx, &sn->rs, &lo);
+    sc s = scan_scalar(run, &sn->rs, &lo);
     u32 cnt = 0;
     int rc;
     for (;;) {
-      rc = ecl_hip_add_range(ctx->dev[w->g], s.w, n, buf, cap, &cnt);
+      rc = ecl_hip_add_range(run->dev[w->g], s.w, n, buf, cap, &cnt);
       if (rc != ECL_E_OVERFLOW) break;
       cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap); /* dense filter: rerun with a buffer that fits */
     }
-    if (rc != ECL_OK) die_ecl(ctx, w->g, rc, "add_range");
+    if (rc != ECL_OK) die_ecl(run, w->g, rc, "add_range");
     u32 kept = 0;
     sc *pks = cnt ? malloc(sizeof(sc) * cnt) : NULL;
     for (u32 i = 0; i < cnt; ++i) {
-      if (!list_confirm(ctx, buf[i].h160)) continue;
-      pks[kept] = calc_priv(s, ctx->stride_k, buf[i].key_offset, buf[i].endo);
+      if (!filter_confirms(&run->flt, buf[i].h160)) continue;
+      pks[kept] = calc_priv(s, run->stride_k, buf[i].key_offset, buf[i].endo);
       buf[kept++] = buf[i];
     }
-    pk_verify_hashes(ctx, w->g, pks, buf, kept);
-    for (u32 i = 0; i < kept; ++i) ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pks[i]);
+    verify_hits(run, w->g, pks, buf, kept);
+    for (u32 i = 0; i < kept; ++i) report_hit(&run->rep, buf[i].compressed, buf[i].h160, &pks[i]);
     free(pks);
-    ctx_update(ctx, st);
+    report_progress(&run->rep, st);
   }
   free(buf);
   return NULL;
@@ -442,10 +526,10 @@ static void *scan_worker(void *arg) {
 /* keys per hand-out.  One GPU: whole sweeps of the walk (2^32 keys at the default geometry), which continue on the
    device without re-initialisation.  Several GPUs: at least two chunks per GPU so that uneven clocks even out, at
    least 2^27 keys (10 ms of kernel against ~0.4 ms of per-call set-up), at most 2^30. */
-static u64 scan_chunk(const ctx_t *ctx, const sc *hashed) {
-  if (ctx->ngpus <= 1) return LAUNCH_KEYS;
+static u64 scan_chunk(const run_t *run, const sc *hashed) {
+  if (run->ngpus <= 1) return LAUNCH_KEYS;
   if (hashed->w[1] | hashed->w[2] | hashed->w[3]) return 1ull << 30;
-  u64 c = (hashed->w[0] + 2 * (u64)ctx->ngpus - 1) / (2 * (u64)ctx->ngpus);
+  u64 c = (hashed->w[0] + 2 * (u64)run->ngpus - 1) / (2 * (u64)run->ngpus);
   c = (c + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
   if (c < (1ull << 27)) c = 1ull << 27;
   if (c > (1ull << 30)) c = 1ull << 30;
@@ -454,7 +538,7 @@ static u64 scan_chunk(const ctx_t *ctx, const sc *hashed) {
 
 /* The plan of one scan: cmd_add (main.c:437-454) over [range_s, range_e) hashes the contiguous run of `hashed` keys from
    range_s and adds `status_total` to the status counter (0: too long to count, added chunk by chunk). */
-static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
+static void scan_plan(run_t *run, sc rs, sc re, bool full_jobs, scan_t *sn) {
   sc span;
   sc_subraw(&span, &re, &rs);
   /* cmd_rnd always uses MAX_JOB_SIZE jobs, even for a narrower window (main.c:624) */
@@ -462,9 +546,9 @@ static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
   u64 job = small ? span.w[0] : MAX_JOB_SIZE; /* main.c:442 */
   /* njobs = ceil(span / (job * stride)) (main.c:420-427): the counter steps by job*stride until it reaches range_e */
   sc njobs = {{0, 0, 0, 0}};
-  if (small && ctx->ord_offs == 0) njobs = sc_u64(1);
+  if (small && run->ord_offs == 0) njobs = sc_u64(1);
   else if (!small) {
-    unsigned sh = 21 + ctx->ord_offs; /* job * stride = 2^sh */
+    unsigned sh = 21 + run->ord_offs; /* job * stride = 2^sh */
     if (sh >= 256) njobs = sc_u64(1);
     else {
       for (unsigned b = sh; b < 256; ++b)
@@ -475,7 +559,7 @@ static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
       if (rem) njobs = sc_add_u64_raw(njobs, 1);
     }
   } else { /* a sub-2^21 job with a stride: step like the reference's counter (at most 2^21 / 2^offs + 1 steps) */
-    sc inc = sc_mul(ctx->stride_k, sc_u64(job)), cur = rs;
+    sc inc = sc_mul(run->stride_k, sc_u64(job)), cur = rs;
     u64 n = 0;
     while (sc_cmp(&cur, &re) < 0 && n < (1u << 22)) {
       sc nx;
@@ -487,7 +571,7 @@ static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
   }
   u64 per_job = (job + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
   memset(sn, 0, sizeof *sn);
-  sn->ctx = ctx, sn->rs = rs, sn->mult = ctx->endo ? 6 : 1;
+  sn->run = run, sn->rs = rs, sn->mult = run->endo ? 6 : 1;
   if (!(njobs.w[1] | njobs.w[2] | njobs.w[3]) && njobs.w[0] < (1ull << 40)) {
     /* the usual case: hashed = (njobs-1)*job + ceil(job/2048)*2048 keys, status counter = njobs*job (x6 with endo) */
     sn->hashed = sc_u64((njobs.w[0] - 1) * job + per_job);
@@ -499,28 +583,28 @@ static void scan_plan(ctx_t *ctx, sc rs, sc re, bool full_jobs, scan_t *sn) {
     for (int i = 0; i < 21; ++i) sc_addraw(&h, &h, &h); /* njobs < 2^235 here: no wrap */
     sn->hashed = h;
   }
-  sn->chunk = scan_chunk(ctx, &sn->hashed);
+  sn->chunk = scan_chunk(run, &sn->hashed);
 }
 
 /* one scan, spread over the GPUs */
-static void scan_range(ctx_t *ctx, sc rs, sc re, bool full_jobs) {
+static void scan_range(run_t *run, sc rs, sc re, bool full_jobs) {
   scan_t sn;
-  scan_plan(ctx, rs, re, full_jobs, &sn);
+  scan_plan(run, rs, re, full_jobs, &sn);
   pthread_mutex_init(&sn.mu, NULL);
   pthread_t th[MAX_GPUS];
   scan_worker_t ws[MAX_GPUS];
-  for (int g = 0; g < ctx->ngpus; ++g) {
+  for (int g = 0; g < run->ngpus; ++g) {
     ws[g] = (scan_worker_t){&sn, g};
     pthread_create(&th[g], NULL, scan_worker, &ws[g]);
   }
-  for (int g = 0; g < ctx->ngpus; ++g) pthread_join(th[g], NULL);
+  for (int g = 0; g < run->ngpus; ++g) pthread_join(th[g], NULL);
   pthread_mutex_destroy(&sn.mu);
 }
 
-static void cmd_add(ctx_t *ctx) {
-  ctx->ts_started = tsnow();
-  scan_range(ctx, ctx->range_s, ctx->range_e, false);
-  ctx_finish(ctx);
+static void cmd_add(run_t *run) {
+  report_restart_clock(&run->rep);
+  scan_range(run, run->range_s, run->range_e, false);
+  report_close(&run->rep);
 }
 
 /* ------------------------------------------------------------------------------------------- mul */
@@ -565,20 +649,20 @@ static void sha256_stream(u32 st[8], const u8 *msg, size_t len) {
   if (total == 128) sha256_block(st, tail + 64);
 }
 
-static void mul_flush(ctx_t *ctx, int g, u64 (*ks)[4], u32 n) {
+static void mul_flush(run_t *run, int g, u64 (*ks)[4], u32 n) {
   if (!n) return;
   u32 cap = n * 2 + 16, cnt = 0;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
-  int rc = ecl_hip_mul_batch(ctx->dev[g], ks, n, buf, cap, &cnt);
-  if (rc != ECL_OK) die_ecl(ctx, g, rc, "mul_batch");
+  int rc = ecl_hip_mul_batch(run->dev[g], ks, n, buf, cap, &cnt);
+  if (rc != ECL_OK) die_ecl(run, g, rc, "mul_batch");
   for (u32 i = 0; i < cnt; ++i) {
-    if (!list_confirm(ctx, buf[i].h160)) continue;
+    if (!filter_confirms(&run->flt, buf[i].h160)) continue;
     sc pk;
     memcpy(pk.w, ks[buf[i].key_offset], 32);
-    ctx_write_found(ctx, buf[i].compressed ? "addr33" : "addr65", buf[i].h160, pk); /* no verify: main.c:469,474 */
+    report_hit(&run->rep, buf[i].compressed, buf[i].h160, &pk); /* no verify: main.c:469,474 */
   }
   free(buf);
-  ctx_update(ctx, n);
+  report_progress(&run->rep, n);
 }
 /* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches.
    The reference parses in its worker threads (main.c:503-527) and is bound by that; here the curve work is on the
@@ -617,9 +701,9 @@ __attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out
 }
 static bool have_ssse3;
 #endif
-static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
+static sc line_to_scalar(const run_t *run, const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
-  if (!ctx->raw_text) { /* fe_modn_from_hex: right to left, non-hex skipped, 64 digits at most */
+  if (!run->opt.raw) { /* fe_modn_from_hex: right to left, non-hex skipped, 64 digits at most */
 #if defined(__x86_64__)
     if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
         hex16_ssse3(p + 48, &k.w[0]))
@@ -642,7 +726,7 @@ static sc line_to_scalar(const ctx_t *ctx, const char *p, size_t len) {
   return k;
 }
 typedef struct {
-  const ctx_t *ctx;
+  const run_t *run;
   const char *buf;
   size_t beg, end;   /* slice [beg, end): starts at a line start, ends after a '\n' (or at the chunk end) */
   u64 (*tmp)[4];     /* this thread's scratch, grown on demand */
@@ -658,7 +742,7 @@ static void *parse_worker(void *arg) {
     if (len && s->buf[at + len - 1] == '\r') len--;
     if (len) {
       if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 32);
-      sc k = line_to_scalar(s->ctx, s->buf + at, len);
+      sc k = line_to_scalar(s->run, s->buf + at, len);
       memcpy(s->tmp[n++], k.w, 32);
     }
     at = stop + 1;
@@ -819,22 +903,22 @@ static void *mul_reader(void *arg) {
 #define MUL_MAX_ARRAYS (MAX_GPUS + 2)
 typedef struct { u64 (*ks)[4]; size_t cap, n; bool pinned; } scalar_array;
 /* scalar arrays live in page-locked memory so that the GPUs read them by DMA (no staging copy in ecl_hip_mul_batch) */
-static void ks_free(const ctx_t *ctx, u64 (*ks)[4], bool pinned) {
-  (void)ctx;
+static void ks_free(const run_t *run, u64 (*ks)[4], bool pinned) {
+  (void)run;
   if (pinned) ecl_hip_free_host(ks);
   else free(ks);
 }
-static void ks_grow(const ctx_t *ctx, scalar_array *ar, size_t n) {
+static void ks_grow(const run_t *run, scalar_array *ar, size_t n) {
   if (n <= ar->cap) return;
-  ks_free(ctx, ar->ks, ar->pinned);
+  ks_free(run, ar->ks, ar->pinned);
   size_t cap = n + n / 8 + 1024;
-  ar->ks = ctx->parse_only ? NULL : ecl_hip_alloc_host(cap * 32);
+  ar->ks = run->parse_only ? NULL : ecl_hip_alloc_host(cap * 32);
   ar->pinned = ar->ks != NULL;
   if (!ar->ks) ar->ks = malloc(cap * 32);
   ar->cap = cap;
 }
 typedef struct {
-  ctx_t *ctx;
+  run_t *run;
   scalar_array arr[MUL_MAX_ARRAYS];
   int narr;
   int ready[MUL_MAX_ARRAYS], nready; /* indices waiting for a device */
@@ -856,12 +940,12 @@ static void *mul_device_worker(void *arg) {
     memmove(q->ready, q->ready + 1, sizeof(int) * --q->nready);
     pthread_mutex_unlock(&q->mu);
     scalar_array *ar = &q->arr[i];
-    if (q->ctx->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
+    if (q->run->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
       for (size_t k = 0; k < ar->n; ++k)
         printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)ar->ks[k][3], (unsigned long long)ar->ks[k][2],
                (unsigned long long)ar->ks[k][1], (unsigned long long)ar->ks[k][0]);
     } else
-      for (size_t at = 0; at < ar->n; at += STEP) mul_flush(q->ctx, a->g, ar->ks + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
+      for (size_t at = 0; at < ar->n; at += STEP) mul_flush(q->run, a->g, ar->ks + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
     pthread_mutex_lock(&q->mu);
     q->idle[q->nidle++] = i;
     pthread_cond_broadcast(&q->cv);
@@ -869,8 +953,8 @@ static void *mul_device_worker(void *arg) {
   }
   return NULL;
 }
-static void cmd_mul(ctx_t *ctx) {
-  ctx->ts_started = tsnow();
+static void cmd_mul(run_t *run) {
+  report_restart_clock(&run->rep);
   hexval_init();
 #if defined(__x86_64__)
   have_ssse3 = __builtin_cpu_supports("ssse3");
@@ -879,18 +963,18 @@ static void cmd_mul(ctx_t *ctx) {
   int P = (int)(ncpu < 1 ? 1 : ncpu > 32 ? 32 : ncpu);
   text_queue tq;
   memset(&tq, 0, sizeof tq);
-  tq.bin = ctx->bin_input;
+  tq.bin = run->bin;
   pthread_mutex_init(&tq.mu, NULL), pthread_cond_init(&tq.cv, NULL);
   for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = malloc(MUL_TEXT_CHUNK);
   scalar_queue sq;
   memset(&sq, 0, sizeof sq);
-  sq.ctx = ctx, sq.narr = ctx->ngpus + 2;
+  sq.run = run, sq.narr = run->ngpus + 2;
   pthread_mutex_init(&sq.mu, NULL), pthread_cond_init(&sq.cv, NULL);
   for (int i = 0; i < sq.narr; ++i) sq.idle[sq.nidle++] = i;
   pthread_t reader, devth[MAX_GPUS];
   mul_dev_arg dargs[MAX_GPUS];
   pthread_create(&reader, NULL, mul_reader, &tq);
-  for (int g = 0; g < ctx->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
+  for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
   parse_slice sl[32];
   memset(sl, 0, sizeof sl);
   pool_t pool;
@@ -907,9 +991,9 @@ static void cmd_mul(ctx_t *ctx) {
     int ai = sq.idle[--sq.nidle];
     pthread_mutex_unlock(&sq.mu);
     scalar_array *ar = &sq.arr[ai];
-    if (ctx->bin_input) { /* the scalars as they are: into the page-locked array, P threads copying */
+    if (run->bin) { /* the scalars as they are: into the page-locked array, P threads copying */
       ar->n = c->len / 32;
-      ks_grow(ctx, ar, ar->n);
+      ks_grow(run, ar, ar->n);
       copy_task ct[32];
       size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
       int nc = 0;
@@ -923,13 +1007,13 @@ static void cmd_mul(ctx_t *ctx) {
         size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
         if (stop <= at) stop = at + 1;
         while (stop < end && c->buf[stop - 1] != '\n') stop++;
-        sl[ns].ctx = ctx, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
+        sl[ns].run = run, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
         at = stop, ns++;
       }
       pool_run(&pool, parse_worker, sl, sizeof sl[0], ns);
       size_t total = 0;
       for (int i = 0; i < ns; ++i) total += sl[i].count;
-      ks_grow(ctx, ar, total);
+      ks_grow(run, ar, total);
       ar->n = total;
       size_t off = 0;
       for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count;
@@ -950,296 +1034,290 @@ static void cmd_mul(ctx_t *ctx) {
   pthread_mutex_unlock(&sq.mu);
   pool_stop(&pool);
   pthread_join(reader, NULL);
-  for (int g = 0; g < ctx->ngpus; ++g) pthread_join(devth[g], NULL);
+  for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
-  for (int i = 0; i < sq.narr; ++i) ks_free(ctx, sq.arr[i].ks, sq.arr[i].pinned);
+  for (int i = 0; i < sq.narr; ++i) ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
   for (int i = 0; i < 32; ++i) free(sl[i].tmp);
-  if (!ctx->parse_only) ctx_finish(ctx);
+  if (!run->parse_only) report_close(&run->rep);
 }
 
 /* ------------------------------------------------------------------------------------------- rnd */
-static u64 rand64(bool urandom) { /* utils.c:83-113 */
-  u64 r = 0;
-  if (urandom) {
-    FILE *f = fopen("/dev/urandom", "rb");
-    if (!f || fread(&r, 8, 1, f) != 1) { fprintf(stderr, "failed to read /dev/urandom\n"); exit(1); }
-    fclose(f);
-    return r;
-  }
-  return (u64)rand() << 32 | (u64)rand();
+/* 64 random bits: /dev/urandom, or - with -seed - pairs of rand() (utils.c:83-113) */
+static u64 random_u64(bool seeded) {
+  if (seeded) return (u64)rand() << 32 | (u64)rand();
+  static FILE *pool;
+  u64 v;
+  if (!pool) pool = fopen("/dev/urandom", "rb");
+  if (!pool || fread(&v, sizeof v, 1, pool) != 1) { fprintf(stderr, "failed to read /dev/urandom\n"); exit(1); }
+  return v;
 }
-static sc sc_rand_range(const sc *a, const sc *b, bool urandom) { /* uniform-ish value in [a, b) (utils.c:115-153) */
-  sc span, r;
-  sc_subraw(&span, b, a);
+/* uniform value in [lo, hi], both inclusive (fe_rand_range, utils.c:115-153: draw as many bits as the span has, reject) */
+static sc random_between(const sc *lo, const sc *hi, bool seeded) {
+  sc span, v;
+  sc_subraw(&span, hi, lo);
+  span = sc_add_u64_raw(span, 1);
   unsigned bits = sc_bitlen(&span);
-  for (;;) {
-    for (int i = 0; i < 4; ++i) r.w[i] = rand64(urandom);
-    for (unsigned i = bits; i < 256; ++i) r.w[i >> 6] &= ~(1ULL << (i & 63));
-    if (sc_cmp(&r, &span) < 0) break;
-  }
-  sc_addraw(&r, &r, a);
-  return r;
-}
-static void print_range_mask(const sc *v, u32 bits_size, u32 offset, bool color) { /* main.c:593-617 */
-  int mask_e = 255 - (int)offset, mask_s = mask_e - (int)bits_size + 1;
-  for (int i = 0; i < 64; i++) {
-    if (i % 16 == 0 && i != 0) putchar(' ');
-    int bs = i * 4, be = bs + 3;
-    u32 nib = (v->w[(255 - be) / 64] >> ((255 - be) % 64)) & 0xF;
-    bool flag = (bs >= mask_s && bs <= mask_e) || (be >= mask_s && be <= mask_e);
-    if (flag && color) fputs("\033[33m", stdout);
-    putchar("0123456789abcdef"[nib]);
-    if (flag && color) fputs("\033[0m", stdout);
-  }
-  putchar('\n');
-}
-/* cmd_rnd (main.c:619-662): random value in [A,B], bits offs..offs+size-1 cleared / set -> window, scanned like add */
-static void cmd_rnd(ctx_t *ctx) {
-  if (ctx->ord_offs > 255 - ctx->ord_size) ctx->ord_offs = 255 - ctx->ord_size;
-  printf("[RANDOM MODE] offs: %d ~ bits: %d\n\n", ctx->ord_offs, ctx->ord_size);
-  ctx->ts_started = tsnow();
-  sc a = ctx->range_s, b = ctx->range_e;
-  const char *mw = getenv("ECLOOP_HIP_RND_WINDOWS");
-  u64 max_windows = mw ? strtoull(mw, NULL, 10) : 0, windows = 0;
-  for (;;) {
-    u64 last_c = ctx->k_checked, last_f = ctx->k_found, t0 = tsnow();
-    sc s = sc_rand_range(&a, &b, !ctx->has_seed), e = s; /* gen_random_range, main.c:580-591 */
-    for (u32 i = ctx->ord_offs; i < ctx->ord_offs + ctx->ord_size; ++i) s.w[i / 64] &= ~(1ULL << (i % 64)), e.w[i / 64] |= 1ULL << (i % 64);
-    if (sc_cmp(&s, &a) <= 0) s = a;
-    if (sc_cmp(&e, &b) >= 0) e = b;
-    print_range_mask(&s, ctx->ord_size, ctx->ord_offs, ctx->use_color);
-    print_range_mask(&e, ctx->ord_size, ctx->ord_offs, ctx->use_color);
-    bool is_full = sc_cmp(&s, &a) == 0 && sc_cmp(&e, &b) == 0;
-    if (sc_cmp(&s, &e) < 0) scan_range(ctx, s, e, true);
-    u64 dc = ctx->k_checked - last_c, df = ctx->k_found - last_f;
-    double dt = (tsnow() - t0 < 1 ? 1 : tsnow() - t0) / 1000.0;
-    term_clear_line();
-    printf("%'llu / %'llu ~ %.1fs\n\n", (unsigned long long)df, (unsigned long long)dc, dt);
-    if (is_full) break;
-    /* the reference loops until interrupted; ECLOOP_HIP_RND_WINDOWS=N (tests, timing runs) stops after N windows */
-    if (max_windows && ++windows >= max_windows) break;
-  }
-  if (getenv("ECLOOP_HIP_STATS")) { /* where the device time of the windows went: search kernel vs per-window set-up */
-    for (int g = 0; g < ctx->ngpus; ++g) {
-      double kms = 0, sms = 0;
-      u64 launches = 0, keys = 0, setups = 0;
-      ecl_hip_get_timing(ctx->dev[g], &kms, &launches, &keys);
-      ecl_hip_get_setup_timing(ctx->dev[g], &sms, &setups);
-      printf("gpu %d: %llu launches, %.3f ms in the search kernel, %llu set-ups, %.3f ms in set-up kernels (%.2f %%)\n", g,
-             (unsigned long long)launches, kms, (unsigned long long)setups, sms, kms > 0 ? 100.0 * sms / (kms + sms) : 0.0);
+  do {
+    for (int i = 0; i < 4; ++i) {
+      unsigned keep = bits > 64u * i ? (bits - 64u * i >= 64 ? 64 : bits - 64u * i) : 0;
+      v.w[i] = keep ? random_u64(seeded) & (keep == 64 ? ~0ULL : (1ULL << keep) - 1) : 0;
     }
+  } while (bits && sc_cmp(&v, &span) >= 0);
+  sc_addraw(&v, &v, lo);
+  return v;
+}
+/* One window of `rnd` (gen_random_range, main.c:580-591): a random value of [A, B] with bits offs .. offs+size-1 cleared
+   is the first key, the same value with those bits set the last; both clamped to [A, B]. */
+typedef struct { sc first, last; } window_t;
+static window_t window_draw(const sc *A, const sc *B, u32 offs, u32 size, bool seeded) {
+  window_t w;
+  w.first = w.last = random_between(A, B, seeded);
+  for (u32 b = offs; b < offs + size; ++b) {
+    const u64 bit = 1ULL << (b & 63);
+    w.first.w[b >> 6] &= ~bit, w.last.w[b >> 6] |= bit;
   }
-  ctx_finish(ctx);
+  if (sc_cmp(&w.first, A) < 0) w.first = *A;
+  if (sc_cmp(&w.last, B) > 0) w.last = *B;
+  return w;
+}
+/* a window bound as the reference prints it (print_range_mask, main.c:593-617): 64 hex digits in four groups, the digits
+   that overlap the window's bit field in yellow on a terminal (digit i from the left holds bits 255-4i-3 .. 255-4i) */
+static void window_print_bound(const sc *v, u32 offs, u32 size, bool colour) {
+  char digits[65];
+  hex_of_scalar(digits, v);
+  const int top = 255 - (int)offs, bottom = top - (int)size + 1; /* in the reference's left-to-right bit numbering */
+  for (int i = 0; i < 64; ++i) {
+    const bool lit = colour && 4 * i + 3 >= bottom && 4 * i <= top;
+    printf("%s%s%c%s", i && i % 16 == 0 ? " " : "", lit ? "\033[33m" : "", digits[i], lit ? "\033[0m" : "");
+  }
+  printf("\n");
+}
+/* cmd_rnd (main.c:619-662): window after window, each scanned like `add -r first:last -d offs:size` with full-size jobs;
+   stops after the first window if that window is the whole range, otherwise runs until interrupted
+   (ECLOOP_HIP_RND_WINDOWS=N, for tests and timing runs, stops after N windows). */
+static void cmd_rnd(run_t *run) {
+  report_t *rep = &run->rep;
+  if (run->ord_offs + run->ord_size > 255) run->ord_offs = 255 - run->ord_size;
+  printf("[RANDOM MODE] offs: %d ~ bits: %d\n\n", run->ord_offs, run->ord_size);
+  report_restart_clock(rep);
+  const sc A = run->range_s, B = run->range_e;
+  const char *limit_text = getenv("ECLOOP_HIP_RND_WINDOWS");
+  const u64 limit = limit_text ? strtoull(limit_text, NULL, 10) : 0;
+  for (u64 done = 0;;) {
+    const u64 found0 = rep->found, checked0 = rep->checked, t0 = ms_now();
+    const window_t w = window_draw(&A, &B, run->ord_offs, run->ord_size, run->seeded);
+    window_print_bound(&w.first, run->ord_offs, run->ord_size, run->colour);
+    window_print_bound(&w.last, run->ord_offs, run->ord_size, run->colour);
+    if (sc_cmp(&w.first, &w.last) < 0) scan_range(run, w.first, w.last, true);
+    const u64 took = ms_now() - t0;
+    erase_status_line();
+    printf("%'llu / %'llu ~ %.1fs\n\n", (unsigned long long)(rep->found - found0), (unsigned long long)(rep->checked - checked0),
+           (took ? took : 1) / 1000.0);
+    const bool whole_range = !sc_cmp(&w.first, &A) && !sc_cmp(&w.last, &B);
+    if (whole_range || (limit && ++done >= limit)) break;
+  }
+  if (getenv("ECLOOP_HIP_STATS")) /* where the device time of the windows went: search kernel vs per-window set-up */
+    for (int g = 0; g < run->ngpus; ++g) {
+      double kernel_ms = 0, setup_ms = 0;
+      u64 launches = 0, keys = 0, setups = 0;
+      ecl_hip_get_timing(run->dev[g], &kernel_ms, &launches, &keys);
+      ecl_hip_get_setup_timing(run->dev[g], &setup_ms, &setups);
+      printf("gpu %d: %llu launches, %.3f ms in the search kernel, %llu set-ups, %.3f ms in set-up kernels (%.2f %%)\n", g,
+             (unsigned long long)launches, kernel_ms, (unsigned long long)setups, setup_ms,
+             kernel_ms > 0 ? 100.0 * setup_ms / (kernel_ms + setup_ms) : 0.0);
+    }
+  report_close(rep);
 }
 
 /* ------------------------------------------------------------------------------------------- blf-gen / blf-check */
-static void blf_gen(args_t *args) { /* utils.c:409-475 */
-  u64 n = args_uint(args, "-n", 0);
-  const char *path = arg_str(args, "-o");
-  if (!n || !path) {
-    fprintf(stderr, "Usage: %s blf-gen -n <count> -o <file>   (hex hash160 list on stdin)\n", args->argv[0]);
+/* hash160 lines of a text stream, a batch at a time (lines are read the way filter_open reads a list: 40-character
+   pieces, clean hex only) */
+typedef struct { FILE *in; char carry[41]; } hash_lines_t;
+static size_t hash_lines_next(hash_lines_t *s, u32 (*out)[5], size_t want) {
+  size_t n = 0;
+  while (n < want && fgets(s->carry, sizeof s->carry, s->in))
+    if (strlen(s->carry) == 40 && hash160_from_hex(s->carry, out[n])) n++;
+  return n;
+}
+/* blf-gen -n <count> -o <file> < hashes (utils.c:409-475): a filter sized for n entries at a false-positive rate of 1e-9,
+   created or - if the file exists with that size - updated; prints how many of the hashes were new.  Filters for 2^16
+   entries and more are filled on the GPU when one is visible (`-host` keeps it on the CPU): the same 20 bits per hash by
+   atomic ORs, and the same "new items" count as the sequential loop gives in input order (ecl_hip_bloom_insert_count);
+   the file written is byte-identical either way. */
+static void cmd_blf_gen(const opts_t *o, const char *prog) {
+  const u64 n = opt_number(o->count, 0);
+  if (!n || !o->outfile) {
+    fprintf(stderr, "Usage: %s blf-gen -n <count> -o <file>   (hex hash160 list on stdin)\n", prog);
     exit(1);
   }
-  u64 r = 1000000000ull;
-  double p = 1.0 / (double)r;
-  u64 m = (u64)(n * log(p) / log(1.0 / pow(2.0, log(2.0))));
-  double mb = (double)m / 8 / 1024 / 1024;
-  u64 size = (m + 63) / 64;
-  blf_t blf = {0, NULL};
-  if (access(path, F_OK) == 0) {
-    printf("file %s already exists; loading...\n", path);
-    if (!blf_load(path, &blf)) { fprintf(stderr, "[!] failed to load bloom filter: delete it or choose a different file\n"); exit(1); }
-    if (blf.size != size) { fprintf(stderr, "[!] bloom filter size mismatch (%'llu != %'llu)\n", (unsigned long long)blf.size, (unsigned long long)size); exit(1); }
+  /* utils.c:421-427, the arithmetic kept operation for operation: its double rounding decides the file size */
+  const u64 one_in = 1000000000ull;
+  const double p = 1.0 / (double)one_in;
+  const u64 m_bits = (u64)(n * log(p) / log(1.0 / pow(2.0, log(2.0))));
+  filter_t f = {NULL, (m_bits + 63) / 64, NULL, 0};
+  if (access(o->outfile, F_OK) == 0) {
+    printf("file %s already exists; loading...\n", o->outfile);
+    filter_t old = {0};
+    if (blf_read(o->outfile, &old)) { fprintf(stderr, "[!] failed to load bloom filter: delete it or choose a different file\n"); exit(1); }
+    if (old.nwords != f.nwords) { fprintf(stderr, "[!] bloom filter size mismatch (%'llu != %'llu)\n", (unsigned long long)old.nwords, (unsigned long long)f.nwords); exit(1); }
+    f.words = old.words;
     printf("updating bloom filter...\n");
   } else {
     printf("creating bloom filter...\n");
-    blf.size = size, blf.bits = calloc(size, 8);
+    f.words = calloc(f.nwords, 8);
   }
-  printf("bloom filter params: n = %'llu | p = 1:%'llu | m = %'llu (%'.1f MB)\n", (unsigned long long)n, (unsigned long long)r, (unsigned long long)m, mb);
-  u64 count = 0;
-  char line[41];
-  /* Filters sized for 2^16 entries and more are filled on the GPU when one is visible (`-host` keeps it here): the
-     same 20 bits per hash by atomic ORs, and the same "new items" count as this loop gives in input order
-     (ecl_hip_bloom_insert_count); the file written is byte-identical either way. */
+  printf("bloom filter params: n = %'llu | p = 1:%'llu | m = %'llu (%'.1f MB)\n", (unsigned long long)n, (unsigned long long)one_in,
+         (unsigned long long)m_bits, (double)m_bits / 8 / 1024 / 1024);
+  hash_lines_t lines = {stdin, ""};
+  u64 fresh = 0;
   ecl_hip *dev = NULL;
-  if (n >= (1u << 16) && !args_bool(args, "-host") && ecl_hip_device_count() > 0) {
+  if (n >= (1u << 16) && !o->host_only && ecl_hip_device_count() > 0) {
     int rc = ecl_hip_open(&dev, 0, ECL_ADDR33, 0);
-    if (rc == ECL_OK) rc = ecl_hip_set_bloom(dev, blf.bits, blf.size);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(dev, f.words, f.nwords);
     if (rc != ECL_OK) { fprintf(stderr, "[!] GPU set-up failed: %s (%s)\n", ecl_hip_strerror(rc), dev ? ecl_hip_last_error(dev) : ""); exit(1); }
     printf("inserting on GPU 0\n");
   }
+  const size_t batch = dev ? (size_t)1 << 22 : 4096;
+  u32 (*hs)[5] = malloc(batch * 20);
+  for (size_t got; (got = hash_lines_next(&lines, hs, batch)) > 0;) {
+    if (dev) {
+      u64 added = 0;
+      int rc = ecl_hip_bloom_insert_count(dev, (const uint32_t(*)[5])hs, got, &added);
+      if (rc != ECL_OK) { fprintf(stderr, "[!] GPU insert failed: %s (%s)\n", ecl_hip_strerror(rc), ecl_hip_last_error(dev)); exit(1); }
+      fresh += added;
+    } else
+      for (size_t i = 0; i < got; ++i)
+        if (!bloom_test(&f, hs[i])) bloom_set(&f, hs[i]), fresh++;
+  }
+  free(hs);
   if (dev) {
-    const size_t BATCH = 1u << 22;
-    u32 (*hs)[5] = malloc(BATCH * 20);
-    size_t have = 0;
-    bool more = true;
-    while (more) {
-      more = fgets(line, sizeof line, stdin) != NULL;
-      if (more && strlen(line) == 40 && parse_hash40(line, hs[have])) have++;
-      if (have == BATCH || (!more && have)) {
-        u64 added = 0;
-        int rc = ecl_hip_bloom_insert_count(dev, (const uint32_t(*)[5])hs, have, &added);
-        if (rc != ECL_OK) { fprintf(stderr, "[!] GPU insert failed: %s (%s)\n", ecl_hip_strerror(rc), ecl_hip_last_error(dev)); exit(1); }
-        count += added, have = 0;
-      }
-    }
-    int rc = ecl_hip_get_bloom(dev, blf.bits, blf.size);
+    int rc = ecl_hip_get_bloom(dev, f.words, f.nwords);
     if (rc != ECL_OK) { fprintf(stderr, "[!] reading the filter back failed: %s\n", ecl_hip_strerror(rc)); exit(1); }
     ecl_hip_close(dev);
-    free(hs);
-  } else
-    while (fgets(line, sizeof line, stdin)) {
-      u32 h[5];
-      if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
-      if (blf_has(&blf, h)) continue;
-      blf_add(&blf, h), count++;
-    }
-  printf("added %'llu new items; saving to %s\n", (unsigned long long)count, path);
-  if (!blf_save(path, &blf)) { fprintf(stderr, "[!] failed to save bloom filter\n"); exit(1); }
-}
-static void blf_check(args_t *args) { /* utils.c:495-529 */
-  const char *path = arg_str(args, "-f");
-  blf_t blf = {0, NULL};
-  if (!path || !blf_load(path, &blf)) { fprintf(stderr, "Usage: %s blf-check -f <file> <hash> [hash...]\n", args->argv[0]); exit(1); }
-  bool any = false;
-  for (int i = 1; i < args->argc; ++i) {
-    u32 h[5];
-    if (strlen(args->argv[i]) != 40 || !parse_hash40(args->argv[i], h)) continue;
-    any = true;
-    printf("%s %s\n", args->argv[i], blf_has(&blf, h) ? "FOUND" : "NOT FOUND");
   }
-  if (any) return;
-  char line[128];
-  while (fgets(line, sizeof line, stdin)) {
-    line[strcspn(line, "\r\n")] = 0;
-    u32 h[5];
-    if (strlen(line) != 40 || !parse_hash40(line, h)) continue;
-    printf("%s %s\n", line, blf_has(&blf, h) ? "FOUND" : "NOT FOUND");
+  printf("added %'llu new items; saving to %s\n", (unsigned long long)fresh, o->outfile);
+  if (!blf_write(o->outfile, &f)) { fprintf(stderr, "[!] failed to save bloom filter\n"); exit(1); }
+}
+/* blf-check -f <file> [hash ...] (utils.c:495-529): the hashes named on the command line, or else those on stdin */
+static void cmd_blf_check(const opts_t *o, int argc, const char **argv) {
+  filter_t f = {0};
+  if (!o->filter || blf_read(o->filter, &f)) { fprintf(stderr, "Usage: %s blf-check -f <file> <hash> [hash...]\n", argv[0]); exit(1); }
+  u32 h[5];
+  int named = 0;
+  for (int i = 2; i < argc; ++i)
+    if (strlen(argv[i]) == 40 && hash160_from_hex(argv[i], h)) printf("%s %s\n", argv[i], bloom_test(&f, h) ? "FOUND" : "NOT FOUND"), named++;
+  if (named) return;
+  char text[128];
+  while (fgets(text, sizeof text, stdin)) {
+    text[strcspn(text, "\r\n")] = 0;
+    if (strlen(text) == 40 && hash160_from_hex(text, h)) printf("%s %s\n", text, bloom_test(&f, h) ? "FOUND" : "NOT FOUND");
   }
 }
 
-/* ------------------------------------------------------------------------------------------- argument handling */
-static void arg_search_range(args_t *args, sc *rs, sc *re) { /* main.c:666-701 */
-  const char *raw = arg_str(args, "-r");
-  if (!raw) { *rs = sc_u64(GROUP_INV_SIZE), *re = SC_P; return; }
-  char *tmp = strdup(raw), *sep = strchr(tmp, ':');
-  if (!sep) { fprintf(stderr, "invalid search range, use format: -r 8000:ffff\n"); exit(1); }
-  *sep = 0;
-  *rs = sc_from_hex(tmp), *re = sc_from_hex(sep + 1);
-  free(tmp);
-  sc lim = sc_u64(GROUP_INV_SIZE);
-  if (sc_cmp(rs, &lim) <= 0) { fprintf(stderr, "invalid search range, start <= %#llx\n", (unsigned long long)GROUP_INV_SIZE); exit(1); }
-  if (sc_cmp(re, &SC_P) > 0) { fprintf(stderr, "invalid search range, end > FE_P\n"); exit(1); }
-  if (sc_cmp(rs, re) >= 0) { fprintf(stderr, "invalid search range, start >= end\n"); exit(1); }
+/* ------------------------------------------------------------------------------------------- range and window arguments */
+/* -r A:B (arg_search_range, main.c:666-701): hex, A > 0x800, B <= p (p, not n), A < B; default 0x800 : p */
+static void range_from_option(const char *text, sc *first, sc *last) {
+  const sc floor = sc_u64(GROUP_INV_SIZE);
+  *first = floor, *last = SC_P;
+  if (!text) return;
+  const char *colon = strchr(text, ':');
+  if (!colon) { fprintf(stderr, "invalid search range, use format: -r 8000:ffff\n"); exit(1); }
+  char *left = strndup(text, (size_t)(colon - text));
+  *first = sc_from_hex(left), *last = sc_from_hex(colon + 1);
+  free(left);
+  const char *why = sc_cmp(first, &floor) <= 0 ? "start <= 0x800" : sc_cmp(last, &SC_P) > 0 ? "end > FE_P" : sc_cmp(first, last) >= 0 ? "start >= end" : NULL;
+  if (why) { fprintf(stderr, "invalid search range, %s\n", why); exit(1); }
 }
-static void load_offs_size(ctx_t *ctx, args_t *args) { /* main.c:703-746 */
-  const u32 MIN_SIZE = 20, MAX_SIZE = 64;
-  u32 range_bits = sc_bitlen(&ctx->range_e);
-  u32 default_bits = range_bits < 32 ? (MIN_SIZE > range_bits ? MIN_SIZE : range_bits) : 32;
-  u32 mx = MIN_SIZE > range_bits ? MIN_SIZE : range_bits;
-  u32 max_offs = mx - default_bits > 1 ? mx - default_bits : 1;
-  const char *raw = arg_str(args, "-d");
-  if (!raw) {
-    ctx->ord_offs = ctx->cmd == CMD_RND ? (u32)(rand64(!ctx->has_seed) % max_offs) : 0;
-    ctx->ord_size = default_bits;
+/* -d offs:size (load_offs_size, main.c:703-746).  size: 20..64, default min(32, max(20, bits of B)); offs: at most 255 and
+   at most max(1, max(20, bits of B) - default size) - so that a window stays inside the range; `rnd` without -d draws
+   the offset at random. */
+static void window_from_option(run_t *run) {
+  const u32 lo_size = 20, hi_size = 64;
+  const u32 span_bits = sc_bitlen(&run->range_e) > lo_size ? sc_bitlen(&run->range_e) : lo_size;
+  const u32 usual = span_bits < 32 ? span_bits : 32;
+  const u32 offs_cap = span_bits - usual > 1 ? span_bits - usual : 1;
+  const char *text = run->opt.window;
+  run->ord_offs = 0, run->ord_size = usual;
+  if (!text) {
+    if (run->cmd == CMD_RND) run->ord_offs = (u32)(random_u64(run->seeded) % offs_cap);
     return;
   }
-  const char *sep = strchr(raw, ':');
-  if (!sep) { fprintf(stderr, "invalid offset:size format, use format: -d 128:32\n"); exit(1); }
-  u32 offs = (u32)atoi(raw), size = (u32)atoi(sep + 1);
+  const char *colon = strchr(text, ':');
+  if (!colon) { fprintf(stderr, "invalid offset:size format, use format: -d 128:32\n"); exit(1); }
+  const u32 offs = (u32)atoi(text), size = (u32)atoi(colon + 1);
   if (offs > 255) { fprintf(stderr, "invalid offset, max is 255\n"); exit(1); }
-  if (size < MIN_SIZE || size > MAX_SIZE) { fprintf(stderr, "invalid size, min is %d and max is %d\n", MIN_SIZE, MAX_SIZE); exit(1); }
-  ctx->ord_offs = offs < max_offs ? offs : max_offs;
-  ctx->ord_size = size;
+  if (size < lo_size || size > hi_size) { fprintf(stderr, "invalid size, min is %d and max is %d\n", lo_size, hi_size); exit(1); }
+  run->ord_offs = offs < offs_cap ? offs : offs_cap, run->ord_size = size;
 }
-static void usage(const char *name) { /* main.c:750-772 */
-  printf("Usage: %s <cmd> [-t <gpus>] [-f <file>] [-a <addr_type>] [-r <range>]\n", name);
-  printf("v%s ~ MI355X build of the ecloop command set\n", VERSION);
-  printf("\nCompute commands:\n");
-  printf("  add             - search in given range with batch addition\n");
-  printf("  mul             - search hex encoded private keys (from stdin)\n");
-  printf("  rnd             - search random range of bits in given range\n");
-  printf("\nCompute options:\n");
-  printf("  -f <file>       - filter file to search (list of hashes or bloom fitler)\n");
-  printf("  -o <file>       - output file to write found keys (default: stdout)\n");
-  printf("  -t <gpus>       - number of GPUs to use (default: all)\n");
-  printf("  -a <addr_type>  - address type to search: c - addr33, u - addr65 (default: c)\n");
-  printf("  -r <range>      - search range in hex format (example: 8000:ffff, default all)\n");
-  printf("  -d <offs:size>  - bit offset and size for search (example: 128:32, default: 0:32)\n");
-  printf("  -q              - quiet mode (no output to stdout; -o required)\n");
-  printf("  -endo           - use endomorphism (default: false)\n");
-  printf("  -bin            - mul: stdin carries 32-byte little-endian scalars instead of hex lines\n");
-  printf("\nOther commands:\n");
-  printf("  blf-gen         - create bloom filter from list of hex-encoded hash160\n");
-  printf("  blf-check       - check bloom filter for given hex-encoded hash160\n");
-  printf("  bench           - run benchmark of the device paths (add per address type / endo, mul)\n\n");
+static void usage(const char *prog) { /* the reference's help text (main.c:750-772) with this program's -t and extras */
+  static const char *const TEXT[] = {
+      "\nCompute commands:\n",
+      "  add             - search in given range with batch addition\n",
+      "  mul             - search hex encoded private keys (from stdin)\n",
+      "  rnd             - search random range of bits in given range\n",
+      "\nCompute options:\n",
+      "  -f <file>       - filter file to search (list of hashes or bloom fitler)\n",
+      "  -o <file>       - output file to write found keys (default: stdout)\n",
+      "  -t <gpus>       - number of GPUs to use (default: all)\n",
+      "  -a <addr_type>  - address type to search: c - addr33, u - addr65 (default: c)\n",
+      "  -r <range>      - search range in hex format (example: 8000:ffff, default all)\n",
+      "  -d <offs:size>  - bit offset and size for search (example: 128:32, default: 0:32)\n",
+      "  -q              - quiet mode (no output to stdout; -o required)\n",
+      "  -endo           - use endomorphism (default: false)\n",
+      "  -bin            - mul: stdin carries 32-byte little-endian scalars instead of hex lines\n",
+      "\nOther commands:\n",
+      "  blf-gen         - create bloom filter from list of hex-encoded hash160\n",
+      "  blf-check       - check bloom filter for given hex-encoded hash160\n",
+      "  bench           - run benchmark of the device paths (add per address type / endo, mul)\n\n"};
+  printf("Usage: %s <cmd> [-t <gpus>] [-f <file>] [-a <addr_type>] [-r <range>]\nv%s ~ MI355X build of the ecloop command set\n", prog, VERSION);
+  for (size_t i = 0; i < sizeof TEXT / sizeof TEXT[0]; ++i) fputs(TEXT[i], stdout);
 }
-/* pause / resume from the terminal (lib/utils.c:559-626, main.c:874-888): /dev/tty in non-canonical mode, one
-   listener thread; 'p' stops the device threads at their next status update, 'r' lets them go on; paused time is
-   taken out of the rate.  Without a controlling terminal (pipes, batch jobs) nothing is installed. */
-static int tty_fd = -1;
-static struct termios tty_orig;
-static bool tty_is_term;
-static void tty_cleanup(void) {
-  if (tty_fd < 0) return;
-  if (tty_is_term) tcsetattr(tty_fd, TCSANOW, &tty_orig);
-  close(tty_fd), tty_fd = -1;
+
+/* ------------------------------------------------------------------------------------------- pause / resume keys */
+/* 'p' parks the device threads at their next progress report, 'r' lets them go on (main.c:874-888; the reference's raw
+   /dev/tty listener is utils.c:546-624).  Keys come from the controlling terminal in non-canonical mode, or from the
+   path in ECLOOP_HIP_TTY (a FIFO works: containers without ptys); without either nothing is installed.  One detached
+   thread polls the descriptor; the terminal's settings are put back at exit. */
+static struct { int fd; bool is_terminal; struct termios saved; report_t *rep; } keys = {-1, false, {0}, NULL};
+static void keys_restore(void) {
+  if (keys.fd < 0) return;
+  if (keys.is_terminal) tcsetattr(keys.fd, TCSANOW, &keys.saved);
+  close(keys.fd), keys.fd = -1;
 }
-static void tty_key(ctx_t *ctx, char ch) {
-  if (ch == 'p' && !ctx->paused) {
-    ctx->ts_paused_at = tsnow(), ctx->paused = true;
-    pthread_mutex_lock(&ctx->lock), ctx_print_unlocked(ctx), pthread_mutex_unlock(&ctx->lock);
-  }
-  if (ch == 'r' && ctx->paused) {
-    ctx->paused_time += tsnow() - ctx->ts_paused_at, ctx->paused = false;
-    pthread_mutex_lock(&ctx->lock), ctx_print_unlocked(ctx), pthread_mutex_unlock(&ctx->lock);
-  }
-}
-static void *tty_listener(void *arg) {
-  ctx_t *ctx = arg;
-  for (;;) {
-    int fd = tty_fd;
-    if (fd < 0) break;
-    fd_set fds;
-    FD_ZERO(&fds);
-    FD_SET(fd, &fds);
-    struct timeval tv = {0, 200000};
-    int r = select(fd + 1, &fds, NULL, NULL, &tv);
-    if (r < 0) break;
-    char ch;
-    if (r > 0 && FD_ISSET(fd, &fds) && read(fd, &ch, 1) > 0) tty_key(ctx, ch);
-  }
+static void *keys_thread(void *unused) {
+  (void)unused;
+  struct pollfd p = {keys.fd, POLLIN, 0};
+  for (char key; p.fd >= 0 && poll(&p, 1, 200) >= 0; p.fd = keys.fd)
+    if ((p.revents & POLLIN) && read(p.fd, &key, 1) == 1 && (key == 'p' || key == 'r')) report_pause(keys.rep, key == 'p');
   return NULL;
 }
-static void tty_init(ctx_t *ctx) {
-  const char *path = getenv("ECLOOP_HIP_TTY"); /* where the keys come from; a FIFO works too (containers without ptys) */
-  tty_fd = open(path ? path : "/dev/tty", (path ? O_RDWR : O_RDONLY) | O_NONBLOCK);
-  if (tty_fd < 0) return;
-  atexit(tty_cleanup);
-  tty_is_term = tcgetattr(tty_fd, &tty_orig) == 0;
-  if (tty_is_term) {
-    struct termios raw = tty_orig;
-    raw.c_lflag &= ~(tcflag_t)(ICANON | ECHO);
-    tcsetattr(tty_fd, TCSANOW, &raw);
-  } else if (!path) {
-    close(tty_fd), tty_fd = -1;
-    return;
+static void keys_listen(report_t *rep) {
+  const char *path = getenv("ECLOOP_HIP_TTY");
+  keys.fd = open(path ? path : "/dev/tty", (path ? O_RDWR : O_RDONLY) | O_NONBLOCK);
+  if (keys.fd < 0) return;
+  keys.rep = rep;
+  keys.is_terminal = tcgetattr(keys.fd, &keys.saved) == 0;
+  if (!keys.is_terminal && !path) { close(keys.fd), keys.fd = -1; return; }
+  atexit(keys_restore);
+  if (keys.is_terminal) {
+    struct termios t = keys.saved;
+    t.c_lflag &= ~(tcflag_t)(ICANON | ECHO);
+    tcsetattr(keys.fd, TCSANOW, &t);
   }
   pthread_t th;
-  if (pthread_create(&th, NULL, tty_listener, ctx) == 0) pthread_detach(th);
+  if (!pthread_create(&th, NULL, keys_thread, NULL)) pthread_detach(th);
 }
-
-static void handle_sigint(int sig) {
+static void on_sigint(int sig) { /* main.c:867-872: what was printed so far reaches its destination, then out */
   fflush(stderr), fflush(stdout);
-  printf("\n");
+  fputc('\n', stdout);
   exit(sig);
 }
 
 /* `bench` (the reference's `bench` / `bench-gtable`, lib/bench.c, time its CPU primitives): here the device paths,
    through the C ABI, with an empty filter: keys/s of the add walk per address / endo selection, scalars/s of mul. */
-static int run_bench(args_t *args) {
+static int run_bench(const opts_t *o) {
   if (ecl_hip_device_count() <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
-  u64 lg = args_uint(args, "-n", 31);
+  u64 lg = opt_number(o->count, 31);
   if (lg < 20 || lg > 36) lg = 31;
   static const struct { const char *name; u32 flags; } cfg[] = {
       {"add -a c", ECL_ADDR33}, {"add -a u", ECL_ADDR65}, {"add -a cu", ECL_ADDR33 | ECL_ADDR65},
@@ -1255,9 +1333,9 @@ static int run_bench(args_t *args) {
     u32 cnt = 0;
     if (rc == ECL_OK) rc = ecl_hip_add_range(d, start, n, hit, 16, &cnt); /* warm-up: table, centres, scratch */
     if (rc == ECL_OK) rc = ecl_hip_reset_timing(d);
-    u64 t0 = tsnow();
+    u64 t0 = ms_now();
     if (rc == ECL_OK) rc = ecl_hip_add_range(d, start, n, hit, 16, &cnt);
-    u64 t1 = tsnow();
+    u64 t1 = ms_now();
     double kms = 0;
     u64 launches = 0, keys = 0;
     if (rc == ECL_OK) rc = ecl_hip_get_timing(d, &kms, &launches, &keys);
@@ -1280,9 +1358,9 @@ static int run_bench(args_t *args) {
     int rc = ecl_hip_open(&d, 0, ECL_ADDR33 | ECL_ADDR65, 0);
     if (rc == ECL_OK) rc = ecl_hip_set_bloom(d, zeros, 64);
     if (rc == ECL_OK) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt); /* warm-up: builds the window table */
-    u64 t0 = tsnow();
+    u64 t0 = ms_now();
     for (int r = 0; r < 4 && rc == ECL_OK; ++r) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt);
-    u64 t1 = tsnow();
+    u64 t1 = ms_now();
     if (rc != ECL_OK) { fprintf(stderr, "[!] bench mul: %s\n", ecl_hip_strerror(rc)); return 1; }
     printf("%-18s 2^22 keys: %9.2f M it/s (scalars copied from host memory)\n", "mul -a cu", 4.0 * n / ((t1 - t0 ? t1 - t0 : 1) / 1000.0) / 1e6);
     free(ks);
@@ -1291,12 +1369,7 @@ static int run_bench(args_t *args) {
   return 0;
 }
 
-typedef struct { ctx_t *ctx; int g, device; u32 flags; u64 share; int rc; u64 t[5]; } open_job;
-static u64 usnow(void) {
-  struct timeval tv;
-  gettimeofday(&tv, NULL);
-  return (u64)tv.tv_sec * 1000000 + tv.tv_usec;
-}
+/* ------------------------------------------------------------------------------------------- device bring-up */
 /* Device contexts of a run: context g works on GPU (g mod shown) mod real, where `shown` is the -t count clamped to
    the visible GPUs and `real` the GPUs that exist.  `mul` opens TWO contexts per GPU - a batch is one synchronous
    ecl_hip_mul_batch call (scalars over PCIe, then the kernel), so the second context's copy runs under the first one's
@@ -1308,152 +1381,150 @@ static int context_devices(int cmd, int shown, int real, int dev_of[MAX_GPUS]) {
   for (int g = 0; g < n; ++g) dev_of[g] = (g % shown) % real;
   return n;
 }
-
-static void *open_worker(void *arg) {
-  open_job *j = arg;
-  ctx_t *ctx = j->ctx;
-  j->t[0] = usnow();
-  int rc = ecl_hip_open(&ctx->dev[j->g], j->device, j->flags, ctx->cmd == CMD_MUL ? 0 : ctx->ord_offs);
-  j->t[1] = usnow();
-  if (rc == ECL_OK) rc = ecl_hip_set_bloom(ctx->dev[j->g], ctx->blf.bits, ctx->blf.size);
-  j->t[2] = usnow();
-  if (rc == ECL_OK && ctx->list) rc = ecl_hip_set_list(ctx->dev[j->g], (const uint32_t(*)[5])ctx->list, ctx->list_count);
-  j->t[3] = usnow();
-  if (rc == ECL_OK && j->share) rc = ecl_hip_reserve(ctx->dev[j->g], j->share, 4096);
-  j->t[4] = usnow();
-  j->rc = rc;
+/* one context: open (self-test once per process), filter upload from the one pinned host copy, optional list, walk
+   buffers of the largest chunk this run will hand out; every step timed for ECLOOP_HIP_STATS */
+typedef struct { run_t *run; int g, device; u32 flags; u64 reserve_keys; int rc; u64 t[5]; } bringup_t;
+static void *bringup_thread(void *arg) {
+  bringup_t *b = arg;
+  run_t *run = b->run;
+  ecl_hip **h = &run->dev[b->g];
+  b->t[0] = us_now();
+  int rc = ecl_hip_open(h, b->device, b->flags, run->cmd == CMD_MUL ? 0 : run->ord_offs);
+  b->t[1] = us_now();
+  if (rc == ECL_OK) rc = ecl_hip_set_bloom(*h, run->flt.words, run->flt.nwords);
+  b->t[2] = us_now();
+  if (rc == ECL_OK && run->flt.list) rc = ecl_hip_set_list(*h, (const uint32_t(*)[5])run->flt.list, run->flt.nlist);
+  b->t[3] = us_now();
+  if (rc == ECL_OK && b->reserve_keys) rc = ecl_hip_reserve(*h, b->reserve_keys, 4096);
+  b->t[4] = us_now();
+  b->rc = rc;
   return NULL;
 }
+/* all contexts at once (every GPU over its own PCIe link), before the status clock starts; returns the seconds it took */
+static double bring_up(run_t *run, int shown, int real) {
+  const u64 t0 = ms_now();
+  int dev_of[MAX_GPUS];
+  run->ngpus = context_devices(run->cmd, shown, real, dev_of);
+  const bool pinned = run->flt.nwords >= (8u << 20) && ecl_hip_pin_host(run->flt.words, run->flt.nwords * 8) == ECL_OK;
+  u64 largest_call = 0;
+  if (run->cmd != CMD_MUL) { /* keys of the largest device call: see scan_chunk() */
+    sc keys;
+    if (run->cmd == CMD_RND) keys = sc_u64(1ull << (run->ord_size < 21 ? 21 : run->ord_size > 62 ? 62 : run->ord_size));
+    else {
+      sc_subraw(&keys, &run->range_e, &run->range_s);
+      for (u32 i = 0; i < run->ord_offs && i < 256; ++i) keys = sc_shr1(keys);
+      keys = sc_add_u64_raw(keys, 4096);
+    }
+    largest_call = scan_chunk(run, &keys);
+    if (!(keys.w[1] | keys.w[2] | keys.w[3]) && keys.w[0] < largest_call) largest_call = keys.w[0];
+  }
+  const u32 flags = (run->a33 ? ECL_ADDR33 : 0) | (run->a65 ? ECL_ADDR65 : 0) | (run->endo ? ECL_ENDO : 0);
+  pthread_t th[MAX_GPUS];
+  bringup_t job[MAX_GPUS];
+  for (int g = 0; g < run->ngpus; ++g) {
+    job[g] = (bringup_t){run, g, dev_of[g], flags, largest_call, ECL_OK, {0}};
+    pthread_create(&th[g], NULL, bringup_thread, &job[g]);
+  }
+  for (int g = 0; g < run->ngpus; ++g) pthread_join(th[g], NULL);
+  for (int g = 0; g < run->ngpus; ++g)
+    if (job[g].rc != ECL_OK) die_ecl(run, g, job[g].rc, "open");
+  if (getenv("ECLOOP_HIP_STATS"))
+    for (int g = 0; g < run->ngpus; ++g)
+      printf("gpu %d bring-up: open %.1f ms, filter upload %.1f ms, list %.1f ms, reserve(%llu keys) %.1f ms\n", g,
+             (job[g].t[1] - job[g].t[0]) / 1e3, (job[g].t[2] - job[g].t[1]) / 1e3, (job[g].t[3] - job[g].t[2]) / 1e3,
+             (unsigned long long)largest_call, (job[g].t[4] - job[g].t[3]) / 1e3);
+  if (pinned) ecl_hip_unpin_host(run->flt.words);
+  return (ms_now() - t0) / 1000.0;
+}
 
+/* ------------------------------------------------------------------------------------------- main */
+static void print_scalar_row(const char *name, const sc *v) {
+  printf("%s: %016llx %016llx %016llx %016llx\n", name, (unsigned long long)v->w[3], (unsigned long long)v->w[2],
+         (unsigned long long)v->w[1], (unsigned long long)v->w[0]);
+}
 int main(int argc, const char **argv) {
   setlocale(LC_NUMERIC, "");
-  args_t args = {argc, argv};
-  static ctx_t ctx;
-  if (argc > 1) {
-    if (!strcmp(argv[1], "blf-gen")) return blf_gen(&args), 0;
-    if (!strcmp(argv[1], "blf-check")) return blf_check(&args), 0;
-    if (!strcmp(argv[1], "bench")) return run_bench(&args);
-    if (!strcmp(argv[1], "parse")) { /* hidden: `mul`'s text front end alone (no GPU), for the parser tests */
-      ctx.cmd = CMD_MUL, ctx.parse_only = true, ctx.ngpus = 1;
-      ctx.raw_text = args_bool(&args, "-raw"), ctx.bin_input = args_bool(&args, "-bin");
-      pthread_mutex_init(&ctx.lock, NULL);
-      cmd_mul(&ctx);
-      return 0;
-    }
-    if (!strcmp(argv[1], "add")) ctx.cmd = CMD_ADD;
-    if (!strcmp(argv[1], "plan")) ctx.cmd = CMD_ADD, ctx.plan_only = true;
-    if (!strcmp(argv[1], "mul")) ctx.cmd = CMD_MUL;
-    if (!strcmp(argv[1], "rnd")) ctx.cmd = CMD_RND;
+  static run_t run;
+  opts_t *o = &run.opt;
+  opts_parse(o, argc, argv);
+  const char *verb = argc > 1 ? argv[1] : "";
+  /* commands that need no search context */
+  if (!strcmp(verb, "blf-gen")) return cmd_blf_gen(o, argv[0]), 0;
+  if (!strcmp(verb, "blf-check")) return cmd_blf_check(o, argc, argv), 0;
+  if (!strcmp(verb, "bench")) return run_bench(o);
+  if (!strcmp(verb, "parse")) { /* hidden: `mul`'s text front end alone (no GPU), for the parser tests */
+    run.cmd = CMD_MUL, run.parse_only = true, run.ngpus = 1, run.bin = o->bin;
+    report_init(&run.rep, NULL, true);
+    cmd_mul(&run);
+    return 0;
   }
-  if (ctx.cmd == CMD_NIL) {
-    if (args_bool(&args, "-v")) printf("ecloop-hip v%s\n", VERSION);
+  const bool plan_only = !strcmp(verb, "plan"); /* hidden: the job arithmetic of `add` / `rnd`, the context -> GPU map; no GPU */
+  run.cmd = !strcmp(verb, "add") || plan_only ? CMD_ADD : !strcmp(verb, "mul") ? CMD_MUL : !strcmp(verb, "rnd") ? CMD_RND : CMD_NIL;
+  if (run.cmd == CMD_NIL) {
+    if (o->version) printf("ecloop-hip v%s\n", VERSION);
     else usage(argv[0]);
     return 0;
   }
-  ctx.use_color = isatty(fileno(stdout));
-  const char *seed = arg_str(&args, "-seed");
-  if (seed) {
+  run.colour = isatty(fileno(stdout));
+  if (o->seed) { /* a seeded run draws from rand() (the reference free()s an argv pointer here and aborts, main.c:800-805) */
     u32 s = 5381;
-    for (const char *c = seed; *c; ++c) s = s * 33 + (u8)*c;
-    ctx.has_seed = true, srand(s); /* the reference free()s an argv pointer here and aborts (main.c:800-805) */
+    for (const char *c = o->seed; *c; ++c) s = s * 33 + (u8)*c;
+    run.seeded = true, srand(s);
   }
-  if (!ctx.plan_only) load_filter(&ctx, arg_str(&args, "-f"));
-  ctx.quiet = args_bool(&args, "-q");
-  const char *outfile = arg_str(&args, "-o");
-  if (outfile) ctx.outfile = fopen(outfile, "a");
-  if (!outfile && ctx.quiet) { fprintf(stderr, "quiet mode chosen without output file\n"); return 1; }
-  const char *addr = arg_str(&args, "-a");
-  if (addr) ctx.a33 = strchr(addr, 'c') != NULL, ctx.a65 = strchr(addr, 'u') != NULL;
-  if (!ctx.a33 && !ctx.a65) ctx.a33 = true;
-  ctx.endo = args_bool(&args, "-endo") && ctx.cmd != CMD_MUL;
-  ctx.raw_text = args_bool(&args, "-raw");
-  ctx.bin_input = args_bool(&args, "-bin") && ctx.cmd == CMD_MUL;
-  pthread_mutex_init(&ctx.lock, NULL);
-  ctx.ts_started = ctx.ts_updated = tsnow();
-  ctx.ts_printed = ctx.ts_started - 5000;
-  arg_search_range(&args, &ctx.range_s, &ctx.range_e);
-  load_offs_size(&ctx, &args);
-  ctx.stride_k = sc_pow2(ctx.cmd == CMD_MUL ? 0 : ctx.ord_offs);
+  if (!plan_only) filter_open(&run.flt, o->filter);
+  if (o->quiet && !o->outfile && !plan_only) { fprintf(stderr, "quiet mode chosen without output file\n"); exit(1); }
+  run.a33 = o->addr ? strchr(o->addr, 'c') != NULL : true, run.a65 = o->addr && strchr(o->addr, 'u');
+  if (!run.a33 && !run.a65) run.a33 = true; /* main.c:825-827 */
+  run.endo = o->endo && run.cmd != CMD_MUL, run.bin = o->bin && run.cmd == CMD_MUL;
+  report_init(&run.rep, o->outfile, o->quiet);
+  range_from_option(o->range, &run.range_s, &run.range_e);
+  window_from_option(&run);
+  run.stride_k = sc_pow2(run.cmd == CMD_MUL ? 0 : run.ord_offs);
 
-  if (ctx.plan_only) { /* hidden `plan`: the job arithmetic of `add` / `rnd` for -r / -d, no GPU (tests) */
-    scan_t sn;
-    ctx.ngpus = (int)args_uint(&args, "-t", 1);
-    if (arg_str(&args, "-visible")) { /* the context -> GPU map of `-t N` on a box with that many GPUs */
-      int real = (int)args_uint(&args, "-visible", 1), shown = ctx.ngpus > real ? real : ctx.ngpus, dev_of[MAX_GPUS];
-      int n = context_devices(args_bool(&args, "-mul") ? CMD_MUL : CMD_ADD, shown, real, dev_of);
+  if (plan_only) {
+    run.ngpus = (int)opt_number(o->gpus, 1);
+    if (o->visible) { /* the context -> GPU map of `-t N` on a box with that many GPUs */
+      int real = (int)opt_number(o->visible, 1), shown = run.ngpus > real ? real : run.ngpus, dev_of[MAX_GPUS];
+      int n = context_devices(o->as_mul ? CMD_MUL : CMD_ADD, shown, real, dev_of);
       printf("contexts %d gpus %d devices", n, shown);
       for (int g = 0; g < n; ++g) printf(" %d", dev_of[g]);
       printf("\n");
       return 0;
     }
-    scan_plan(&ctx, ctx.range_s, ctx.range_e, args_bool(&args, "-rnd"), &sn);
-    printf("ord_offs %u ord_size %u hashed %016llx%016llx%016llx%016llx status_total %llu chunk %llu\n", ctx.ord_offs, ctx.ord_size,
+    scan_t sn;
+    scan_plan(&run, run.range_s, run.range_e, o->rnd_jobs, &sn);
+    printf("ord_offs %u ord_size %u hashed %016llx%016llx%016llx%016llx status_total %llu chunk %llu\n", run.ord_offs, run.ord_size,
            (unsigned long long)sn.hashed.w[3], (unsigned long long)sn.hashed.w[2], (unsigned long long)sn.hashed.w[1],
            (unsigned long long)sn.hashed.w[0], (unsigned long long)sn.status_total, (unsigned long long)sn.chunk);
     return 0;
   }
-  int have = ecl_hip_device_count(), real = have;
-  /* test hook: ECLOOP_HIP_SHARE_GPU=N runs N device threads over the GPUs that exist (device g mod count), so the
-     multi-GPU sharding / merging logic can be exercised on a one-GPU box */
-  if (have > 0 && getenv("ECLOOP_HIP_SHARE_GPU")) have = atoi(getenv("ECLOOP_HIP_SHARE_GPU")) > 0 ? atoi(getenv("ECLOOP_HIP_SHARE_GPU")) : have;
-  if (have <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
-  u64 want = args_uint(&args, "-t", (u64)have);
-  ctx.ngpus = (int)(want < 1 ? 1 : want > (u64)have ? (u64)have : want);
-  if (ctx.ngpus > MAX_GPUS) ctx.ngpus = MAX_GPUS;
-  int gpus_shown = ctx.ngpus, dev_of[MAX_GPUS];
-  ctx.ngpus = context_devices(ctx.cmd, gpus_shown, real, dev_of);
-  /* Device bring-up, all GPUs at once (one host thread each): context, filter upload from the one pinned host copy
-     (every GPU over its own PCIe link), optional list, and the walk buffers of the chunks this scan will hand out -
-     all before the clock of the status line starts; the time it took is printed in the banner. */
-  u64 t_setup0 = tsnow();
-  bool pinned = ctx.blf.size >= (8u << 20) && ecl_hip_pin_host(ctx.blf.bits, ctx.blf.size * 8) == ECL_OK;
-  {
-    pthread_t th[MAX_GPUS];
-    open_job jobs[MAX_GPUS];
-    u64 share = 0;
-    if (ctx.cmd != CMD_MUL) {
-      /* keys of the largest device call: see scan_chunk() */
-      sc hashed;
-      if (ctx.cmd == CMD_RND) hashed = sc_u64(1ull << (ctx.ord_size < 21 ? 21 : ctx.ord_size > 62 ? 62 : ctx.ord_size));
-      else {
-        sc_subraw(&hashed, &ctx.range_e, &ctx.range_s);
-        for (u32 i = 0; i < ctx.ord_offs && i < 256; ++i) hashed = sc_shr1(hashed);
-        hashed = sc_add_u64_raw(hashed, 4096);
-      }
-      share = scan_chunk(&ctx, &hashed);
-      if (!(hashed.w[1] | hashed.w[2] | hashed.w[3]) && hashed.w[0] < share) share = hashed.w[0];
-    }
-    for (int g = 0; g < ctx.ngpus; ++g) {
-      jobs[g] = (open_job){&ctx, g, dev_of[g], (ctx.a33 ? ECL_ADDR33 : 0) | (ctx.a65 ? ECL_ADDR65 : 0) | (ctx.endo ? ECL_ENDO : 0), share, ECL_OK};
-      pthread_create(&th[g], NULL, open_worker, &jobs[g]);
-    }
-    for (int g = 0; g < ctx.ngpus; ++g) pthread_join(th[g], NULL);
-    for (int g = 0; g < ctx.ngpus; ++g)
-      if (jobs[g].rc != ECL_OK) die_ecl(&ctx, g, jobs[g].rc, "open");
-    if (getenv("ECLOOP_HIP_STATS"))
-      for (int g = 0; g < ctx.ngpus; ++g)
-        printf("gpu %d bring-up: open %.1f ms, filter upload %.1f ms, list %.1f ms, reserve(%llu keys) %.1f ms\n", g,
-               (jobs[g].t[1] - jobs[g].t[0]) / 1e3, (jobs[g].t[2] - jobs[g].t[1]) / 1e3, (jobs[g].t[3] - jobs[g].t[2]) / 1e3,
-               (unsigned long long)share, (jobs[g].t[4] - jobs[g].t[3]) / 1e3);
-  }
-  if (pinned) ecl_hip_unpin_host(ctx.blf.bits);
-  double setup_s = (tsnow() - t_setup0) / 1000.0;
-  printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", gpus_shown, ctx.a33, ctx.a65, ctx.endo);
-  if (ctx.list) printf("list (%'llu)\n", (unsigned long long)ctx.list_count);
+  const int real = ecl_hip_device_count();
+  int usable = real;
+  /* test hook: ECLOOP_HIP_SHARE_GPU=N runs N device threads over the GPUs that exist, so the sharding / merging logic
+     can be exercised on a one-GPU box */
+  const char *share = getenv("ECLOOP_HIP_SHARE_GPU");
+  if (real > 0 && share && atoi(share) > 0) usable = atoi(share);
+  if (real <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
+  u64 asked = opt_number(o->gpus, (u64)usable);
+  int shown = (int)(asked < 1 ? 1 : asked > (u64)usable ? (u64)usable : asked);
+  if (shown > MAX_GPUS) shown = MAX_GPUS;
+  const double setup_s = bring_up(&run, shown, real);
+
+  printf("gpus: %d ~ addr33: %d ~ addr65: %d ~ endo: %d | filter: ", shown, run.a33, run.a65, run.endo);
+  if (run.flt.list) printf("list (%'llu)\n", (unsigned long long)run.flt.nlist);
   else printf("bloom\n");
-  if (ctx.cmd == CMD_ADD) {
-    printf("range_s: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_s.w[3], (unsigned long long)ctx.range_s.w[2], (unsigned long long)ctx.range_s.w[1], (unsigned long long)ctx.range_s.w[0]);
-    printf("range_e: %016llx %016llx %016llx %016llx\n", (unsigned long long)ctx.range_e.w[3], (unsigned long long)ctx.range_e.w[2], (unsigned long long)ctx.range_e.w[1], (unsigned long long)ctx.range_e.w[0]);
-  }
-  printf("setup: %.2fs (%d device context%s opened in parallel, %.0f MB filter uploaded, walk buffers reserved)\n", setup_s, ctx.ngpus,
-         ctx.ngpus == 1 ? "" : "s", ctx.blf.size * 8 / 1e6);
-  printf("----------------------------------------\n");
+  if (run.cmd == CMD_ADD) print_scalar_row("range_s", &run.range_s), print_scalar_row("range_e", &run.range_e);
+  printf("setup: %.2fs (%d device context%s opened in parallel, %.0f MB filter uploaded, walk buffers reserved)\n", setup_s, run.ngpus,
+         run.ngpus == 1 ? "" : "s", run.flt.nwords * 8 / 1e6);
+  puts("----------------------------------------");
   fflush(stdout);
-  signal(SIGINT, handle_sigint);
-  tty_init(&ctx);
-  if (ctx.cmd == CMD_ADD) cmd_add(&ctx);
-  if (ctx.cmd == CMD_MUL) cmd_mul(&ctx);
-  if (ctx.cmd == CMD_RND) cmd_rnd(&ctx);
-  for (int g = 0; g < ctx.ngpus; ++g) ecl_hip_close(ctx.dev[g]);
+  signal(SIGINT, on_sigint);
+  keys_listen(&run.rep);
+  switch (run.cmd) {
+  case CMD_ADD: cmd_add(&run); break;
+  case CMD_MUL: cmd_mul(&run); break;
+  default: cmd_rnd(&run); break;
+  }
+  for (int g = 0; g < run.ngpus; ++g) ecl_hip_close(run.dev[g]);
   return 0;
 }
