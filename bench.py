@@ -605,7 +605,8 @@ def main():
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()
-            torch.cuda.set_device(local)
+            if local < torch.cuda.device_count():  # otherwise: refused below (or folded onto the GPUs that exist by the test hook)
+                torch.cuda.set_device(local)
     if not fake and local == 0:
         from ecloop_amd.build import build_library
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""`mul` path throughput (BASELINE.json configs[4]): 2^22 seeded 256-bit scalars per batch through ecl_hip_mul_batch
-(host -> device copy of the scalars included), addr33 + addr65, list filter of the brainwallet hashes."""
+"""`mul` path throughput (BASELINE.json configs[4]): seeded 256-bit scalars through ecl_hip_mul_batch from a page-locked
+array (host -> device copy of the scalars included), addr33 + addr65, list filter of the brainwallet hashes.  Prints the
+wall rate of each call and the device-side rate (HIP events over the copies + kernels of the call); the first call
+includes building the window table.  ECLOOP_HIP_LIB selects an A/B build (tools/sweep_mul_w.sh: -DMUL_W=...)."""
+import ctypes as C
 import os
 import sys
 import time
@@ -13,16 +16,24 @@ from ecloop_amd import capi  # noqa: E402
 from ecloop_amd.engine import load_filter  # noqa: E402
 
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 flt = load_filter(os.path.join(ROOT, "tests", "golden", "btc-bw-hash"))
 d = capi.Device(0, a33=True, a65=True)
 d.set_bloom(flt.words)
 rng = np.random.RandomState(1)
-K = rng.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+ptr = d.lib.ecl_hip_alloc_host(n * 32)
+assert ptr
+K = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(n, 4))
+K[:] = rng.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
 out = np.zeros(4096, dtype=capi.FOUND_DTYPE)
-cnt = capi.C.c_uint32()
-for it in range(3):
+cnt = C.c_uint32()
+prev = 0.0
+for it in range(calls):
     t0 = time.perf_counter()
-    rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, 4096, capi.C.byref(cnt))
+    rc = d.lib.ecl_hip_mul_batch(d.h, ptr, n, out.ctypes.data, 4096, C.byref(cnt))
     dt = time.perf_counter() - t0
     assert rc == 0
-    print(f"mul_batch: {n} scalars, a33+a65: {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} Mkeys/s (hits {cnt.value})")
+    ms = d.mul_timing()[0]
+    print(f"mul_batch: {n} scalars, a33+a65: wall {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M/s; device {ms-prev:.2f} ms -> {n/(ms-prev)/1e3:.1f} M/s (hits {cnt.value})")
+    prev = ms
+d.lib.ecl_hip_free_host(ptr)
