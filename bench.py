@@ -210,7 +210,7 @@ def add_roofline(ms_launch, keys_per_launch):
     keys_s = keys_per_launch / (ms_launch * 1e-3) if ms_launch > 0 else 0.0
     r = {"bound": "valu-int32", "kernel": "k_add<addr33>", "unit": "T lane-ops/s", "peak": round(PEAK_2CYCLE, 2),
          "peak_definition": "MI355X_MICROARCH.md: wave64 VALU instruction over 2 clocks = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; measured "
-                            "(profiles/ubench_r02.txt) only for add/sub/and/or/xor/mov/not/shift/bitop3 (2.3-2.6 clocks in long runs); rotates, "
+                            "(profiles/ubench_r03.txt) only for add/sub/and/or/xor/mov/not/shift/bitop3 (2.3-2.6 clocks in long runs); rotates, "
                             "v_add3, v_perm, v_bfe, 32-bit multiplies, v_mad_u64_u32, carries take >= 4.1",
          "ms_per_launch": round(ms_launch, 3), "keys_per_launch": int(keys_per_launch), "kernel_mkeys_s": round(keys_s / 1e6, 2),
          "static": fp}

@@ -58,19 +58,40 @@ FE_FN void fe_st_words2(uint4* p, size_t stride, fe a) {  // normalises
   p[0] = make_uint4(w[0], w[1], w[2], w[3]);
   p[stride] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// raw limbs (any magnitude) in planes uint4, uint4, u32
+// raw limbs (any magnitude) in planes uint4, uint4, u32.  These are the prefix-product chain's accesses: every element is
+// written once and read once, a whole group later - a stream with no reuse in any cache.  ECL_CHAIN_NT (A/B builds) marks
+// the loads (bit 0) and / or the stores (bit 1) non-temporal (`nt`: the L1 is bypassed, the L2 / Infinity Cache line is
+// first in line for eviction), so that the stream does not displace the bloom filter's lines.
+#ifndef ECL_CHAIN_NT
+#define ECL_CHAIN_NT 0
+#endif
+#if defined(__HIPCC__)
+typedef u32 ecl_v4u __attribute__((ext_vector_type(4)));
+#endif
 FE_FN fe fe_ld_limbs(const uint4* p4, size_t stride4, const u32* p1) {
-  uint4 a = p4[0], b = p4[stride4];
   fe r;
+#if defined(__HIPCC__) && (ECL_CHAIN_NT & 1)
+  const ecl_v4u a = __builtin_nontemporal_load((const ecl_v4u*)p4), b = __builtin_nontemporal_load((const ecl_v4u*)(p4 + stride4));
+  r.n[8] = __builtin_nontemporal_load(p1);
+#else
+  const uint4 a = p4[0], b = p4[stride4];
+  r.n[8] = p1[0];
+#endif
   r.n[0] = a.x, r.n[1] = a.y, r.n[2] = a.z, r.n[3] = a.w;
   r.n[4] = b.x, r.n[5] = b.y, r.n[6] = b.z, r.n[7] = b.w;
-  r.n[8] = p1[0];
   return r;
 }
 FE_FN void fe_st_limbs(uint4* p4, size_t stride4, u32* p1, const fe& a) {
+#if defined(__HIPCC__) && (ECL_CHAIN_NT & 2)
+  const ecl_v4u lo = {a.n[0], a.n[1], a.n[2], a.n[3]}, hi = {a.n[4], a.n[5], a.n[6], a.n[7]};
+  __builtin_nontemporal_store(lo, (ecl_v4u*)p4);
+  __builtin_nontemporal_store(hi, (ecl_v4u*)(p4 + stride4));
+  __builtin_nontemporal_store(a.n[8], p1);
+#else
   p4[0] = make_uint4(a.n[0], a.n[1], a.n[2], a.n[3]);
   p4[stride4] = make_uint4(a.n[4], a.n[5], a.n[6], a.n[7]);
   p1[0] = a.n[8];
+#endif
 }
 // Table entries are read through the constant address space: the address is wave-uniform (kernel argument + loop
 // counter), so these become scalar loads (s_load_dwordx*) into SGPRs and everything computed from them alone

@@ -55,7 +55,19 @@ FE_FN u64 bloom_index(const u64 a[5], int probe) {
   const int j = probe % 5;
   return a[j] << S | a[(j + 1) % 5] >> S;
 }
-FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (b.bits[bloom_mod(b, idx >> 6)] >> (idx & 63)) & 1; }
+// ECL_PROBE_NT (A/B builds): the probe's 8-byte load marked non-temporal (bypasses the per-CU L1, where a random probe
+// into a filter of tens of MB never hits anyway)
+#ifndef ECL_PROBE_NT
+#define ECL_PROBE_NT 0
+#endif
+FE_FN u64 bloom_word(const bloom_t& b, u64 w) {
+#if defined(__HIPCC__) && ECL_PROBE_NT
+  return __builtin_nontemporal_load(b.bits + w);
+#else
+  return b.bits[w];
+#endif
+}
+FE_FN bool bloom_bit(const bloom_t& b, u64 idx) { return (bloom_word(b, bloom_mod(b, idx >> 6)) >> (idx & 63)) & 1; }
 
 // lib/utils.c:308-326 in stages.  Stage 1: probe 0 alone (at the `.blf` design density 0.375 it rejects 62 % of the
 // hashes; ECL_STAGE1_PROBES = 2 would issue probes 0 and 1 together and reject 86 %).  Then the remaining probes, one

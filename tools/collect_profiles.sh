@@ -6,7 +6,7 @@
 # 2^32-key launch each (ECL_HIP_SKIP_SELFTEST=1: no 4096-key self-test launch in the counters).
 # Copy what is to be kept into profiles/ (tracked); bench.py reads profiles/<tag>_roofline.json.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$(pwd)
 O=$R/gpurun_out/prof_$TAG
@@ -87,13 +87,14 @@ cd "$R"
 python tools/make_roofline_profile.py "$O" "$TAG" > "$O/${TAG}_roofline.json" 2> "$O/make_profile.err"
 python - "$O/pmc_mul.txt" "$TAG" > "$O/${TAG}_mul.json" <<'PY'
 import json, sys
-pmc, ns = {}, []
+pmc, ns, passes = {}, [], 0
 for line in open(sys.argv[1]):
     f = line.split()
+    if line.startswith("# --pmc"): passes += 1
     if f and f[0] == "PMC": pmc[f[2]] = (float(f[3]), int(f[4]))
     if f and f[0] == "TRACE": ns.append(int(f[2]))
 scalars = 2 * (1 << 24)  # warm-up + one step
-out = {"tag": sys.argv[2], "kernel": "k_mul_check<addr33,addr65>", "workload": "bench.py --cmd mul: 2^24 scalars per step, -a cu, R = 16 scalars per thread",
+out = {"tag": sys.argv[2], "kernel": "k_mul_check<addr33,addr65>", "workload": "bench.py --cmd mul: 2^24 scalars per step, -a cu, R = 16 scalars per thread, window table W = 22 (12 additions per scalar)",
        "pmc": {k: v[0] for k, v in pmc.items()}, "dispatches": {k: v[1] for k, v in pmc.items()}, "derived": {}}
 if "SQ_INSTS_VALU" in pmc:
     out["derived"]["valu_lane_ops_per_scalar"] = pmc["SQ_INSTS_VALU"][0] * 64 / scalars
@@ -101,8 +102,9 @@ if "FETCH_SIZE" in pmc:
     out["derived"]["fetch_bytes_per_scalar_reported"] = pmc["FETCH_SIZE"][0] * 1024 / scalars
 if "VALUBusy" in pmc:
     out["derived"]["valu_busy_pct"] = pmc["VALUBusy"][0] / max(pmc["VALUBusy"][1], 1)
-if ns:
-    out["derived"]["kernel_ms_per_2^22_scalars"] = sum(ns) / len(ns) / 1e6
+if ns and passes:  # a call is cut into chunks of unequal size (the first is a quarter): total kernel time over total scalars
+    out["derived"]["kernel_ms_per_2^22_scalars"] = sum(ns) / (passes * scalars) * (1 << 22) / 1e6
+    out["derived"]["kernel_mscalars_s"] = passes * scalars / sum(ns) * 1e3
 print(json.dumps(out, indent=1))
 PY
 cp "$O/${TAG}_mul.json" "profiles/${TAG}_mul.json"
