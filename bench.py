@@ -412,12 +412,18 @@ def bench_mul(args, sync, dev_index, emit):
             raise SystemExit("[bench] cannot pin the scalar array")
     out = np.zeros(64, dtype=np.dtype([("b", "u1", (32,))]))
     cnt = C.c_uint32()
+    # steady state of a long run: the 22-bit window table at once (left alone a context starts on 18 bits and moves to 22
+    # after 2^29 scalars - more than this bench multiplies); `--mul-window 0` measures the automatic choice instead
+    ks.dev.set_mul_window(args.mul_window)
+    t_tab = time.perf_counter()
 
     def step():
         rc = lib.ecl_hip_mul_batch(h, scal.ctypes.data, n, out.ctypes.data, 64, C.byref(cnt))
         if rc not in (0, -4):
             raise SystemExit(f"[bench] mul_batch failed: {rc}")
 
+    step()  # builds the table
+    t_first = time.perf_counter() - t_tab
     for _ in range(max(args.warmup, 1)):
         step()
     ks.dev.reset_timing()
@@ -439,7 +445,8 @@ def bench_mul(args, sync, dev_index, emit):
            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
            "config": {"workload": f"mul -a {addr}: 2^{args.mul_log2} seeded 256-bit scalars per GPU per step from HOST memory through "
                                   "ecl_hip_mul_batch (copies overlapped with the kernel), empty filter", "hashes_per_scalar": hashes,
-                      "host_memory": "pageable (staged)" if args.pageable else "page-locked (direct DMA)", "launcher": sync.kind},
+                      "host_memory": "pageable (staged)" if args.pageable else "page-locked (direct DMA)", "launcher": sync.kind,
+                      "window_bits": ks.dev.mul_window(), "first_call_ms_incl_table_build": round(t_first * 1e3, 1)},
            "roofline": {"bound": "valu-int32", "kernel": "k_mul_check", "ms_per_call_on_stream": round(ms / max(calls, 1), 3),
                         "device_mscalars_s": round(nsc / (ms * 1e-3) / 1e6, 2) if ms else None,
                         "pcie_gbs": round(nsc * 32 / (ms * 1e-3) / 1e9, 2) if ms else None}}
@@ -586,6 +593,7 @@ def main():
     ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
     ap.add_argument("--cmd", default="add", choices=["add", "mul"], help="mul: the non-headline `mul` path")
     ap.add_argument("--mul-log2", type=int, default=24)
+    ap.add_argument("--mul-window", type=int, default=22, help="mul: window width of the table (0 = the library's automatic choice)")
     ap.add_argument("--pageable", action="store_true", help="mul: scalars in pageable host memory (staged through pinned buffers by the library)")
     args = ap.parse_args()
     t_process = time.perf_counter()

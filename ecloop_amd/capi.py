@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
 ]
 
 _lib = None
@@ -67,6 +67,8 @@ def load():
     lib.ecl_hip_get_mul_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
     lib.ecl_hip_unpin_host.argtypes = [C.c_void_p]
+    lib.ecl_hip_set_mul_window.argtypes = [P, C.c_uint32]
+    lib.ecl_hip_get_mul_window.argtypes = [P, C.POINTER(C.c_uint32)]
     lib.ecl_hip_verify.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ecl_hip_alloc_host.argtypes = [C.c_size_t]
     lib.ecl_hip_alloc_host.restype = C.c_void_p
@@ -180,6 +182,15 @@ class Device:
         rc = self.lib.ecl_hip_mul_batch(self.h, k.ctypes.data, len(k), out.ctypes.data, cap, C.byref(n))
         self._chk(rc, allow=(E_OVERFLOW,))
         return out[: min(n.value, cap)], n.value
+
+    def set_mul_window(self, bits):
+        """window width of this context's `mul` table (8..24; 0 = automatic: 18, then 22 after 2^29 scalars)"""
+        self._chk(self.lib.ecl_hip_set_mul_window(self.h, bits))
+
+    def mul_window(self):
+        bits = C.c_uint32()
+        self._chk(self.lib.ecl_hip_get_mul_window(self.h, C.byref(bits)))
+        return bits.value
 
     def verify(self, ks):
         """pk_verify_hash for a batch: -> (h33, h65, ok) of the scalars' public keys (window-table path)"""

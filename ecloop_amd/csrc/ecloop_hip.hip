@@ -147,32 +147,57 @@ __device__ __forceinline__ jac gtable_sum(const u32 kk[9], const u32* __restrict
 }
 __device__ __forceinline__ jac gtable_mul(const u32 kk[9], const u32* __restrict__ gtab) { return gtable_sum<GT_W, GT_WINDOWS>(kk, gtab); }
 
-// ---- `mul` has its own, HBM-sized window table.  The reference's W = 14 (19 windows, 19.9 MB) is sized for a CPU's
+// ---- `mul` has its own window tables, sized for HBM.  The reference's W = 14 (19 windows, 19.9 MB) is sized for a CPU's
 // cache (lib/ecc.c:876, `bench-gtable` sweeps it); on a 288 GB part W = 22 costs 3.0 GB and turns 19 additions per
 // scalar into 12 (one per non-zero digit).  Same method, same results; measured on 2^24-scalar calls, -a cu, device
-// time: W = 14 700 M scalars/s, 16 775, 18 800, 20 846, 22 880, 24 (11.8 GB) 925 (profiles/r03_mul_w_sweep.txt).
+// time: W = 14 725 M scalars/s, 16 811, 18 842, 20 878, 22 919, 24 (11.8 GB) 965 (profiles/r03_mul_w_sweep.txt).
+// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 18, 252 MB,
+// built in a few ms, and moves to W = 22 once it has seen enough scalars to pay for the 50 ms build: ecl_hip_mul_batch).
 // The rows are not built by millions of double-and-add ladders but the way the walk's lane centres are: row w is
 // P_w, 2 P_w, 3 P_w, ... with P_w = 2^(W w) G - the points C0 + g D of k_init_centres_batched with C0 = D = P_w -
 // 44 multiplications per entry, one inversion per 16 entries; the ladder points 2^j P_w of every row come from one
 // k_mul_g launch.
-#ifndef MUL_W
-#define MUL_W 22u
-#endif
-#define MUL_WINDOWS ((256u + MUL_W - 1u) / MUL_W)
-#define MUL_PER ((1u << MUL_W) - 1u)
-#define MUL_TOP_BITS (256u - MUL_W * (MUL_WINDOWS - 1u))   /* digits of the last window are narrower */
-#define MUL_TOP_PER ((1u << MUL_TOP_BITS) - 1u)
-#define MUL_SLOTS ((size_t)(MUL_WINDOWS - 1u) * MUL_PER + MUL_TOP_PER)
-// row w = blockIdx.y: out[w * PER + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
+struct wtab {
+  const u32* p;  // slot per * w + b - 1 = b * 2^(W w) * G, canonical x[8], y[8]
+  u32 W, nwin, per, top_per;  // bits per window, windows = ceil(256 / W), 2^W - 1, entries of the last row
+};
+__host__ __device__ inline wtab wtab_make(const u32* p, u32 W) {
+  wtab t;
+  t.p = p, t.W = W, t.nwin = (256u + W - 1u) / W, t.per = (1u << W) - 1u;
+  t.top_per = (1u << (256u - W * (t.nwin - 1u))) - 1u;
+  return t;
+}
+__host__ __device__ inline size_t wtab_slots(const wtab& t) { return (size_t)(t.nwin - 1u) * t.per + t.top_per; }
+__device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 bit = w * t.W, word = bit >> 5, sh = bit & 31;
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
+      if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+    }
+    const u32 digit = (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // kk[8] = 0: the last window is as narrow as it is
+    if (!digit) continue;
+    const u32* e = t.p + ((size_t)w * t.per + digit - 1) * 16;
+    acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
+  }
+  return acc;
+}
+// rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
 // consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
-__global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt) {
-  const u32 w = blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
-  const u32 count = w == MUL_WINDOWS - 1u ? MUL_TOP_PER : MUL_PER;
+__global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
+                                                      u32 W, u32 w0) {
+  const wtab tb = wtab_make(table, W);
+  const u32 w = w0 + blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
+  const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
   const u32 g0 = t * 16u;
   if (t >= nt || g0 >= count) return;
   const u32* ladder = ladders + (size_t)w * 32 * 16;
-  u32* out = table + (size_t)w * MUL_PER * 16;
-  u32* tmp = tmp_all + (size_t)w * 16 * 36 * nt;
+  u32* out = table + (size_t)w * tb.per * 16;
+  u32* tmp = tmp_all + (size_t)blockIdx.y * 16 * 36 * nt;
   jac acc;
   acc.X = fe_ldw(ladder), acc.Y = fe_ldw(ladder + 8), acc.Z = fe_one(), acc.inf = 0;
 #pragma unroll 1
@@ -228,10 +253,10 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // One thread owns MUL_R scalars (i = t, t + nt, ...: a wave reads 2 KiB of contiguous scalars per round): their window
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
-// the reference's 2048-key job): 209 + 17 + 7 multiplications per scalar instead of 209 + 270 + 3.
+// the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
 #define MUL_R 16u  /* at most; short batches take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 template <bool A33, bool A65>
-__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const u32* __restrict__ gtab, add_args a,
+__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt) return;
@@ -244,7 +269,7 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
     u32 kk[9];
     const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
     kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
-    const jac acc = gtable_sum<MUL_W, MUL_WINDOWS>(kk, gtab);
+    const jac acc = wtab_sum(kk, gtab);
     const fe z = acc.inf ? fe_one() : acc.Z;
     infmask |= (acc.inf ? 1u : 0u) << r;
     u32* p = tmp + (size_t)r * 36 * nt + t;
@@ -472,7 +497,9 @@ struct ecl_hip {
   // `mul`: scalars travel in chunks through two pinned staging buffers, copy engine and kernel overlapped
   u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr}; u32 kbuf_cap = 0, pin_cap = 0;
   u32* d_multmp = nullptr;                     // parked Jacobian sums of one chunk (144 bytes per scalar)
-  const u32* d_multab = nullptr;               // `mul`'s HBM-sized window table: one per device, shared by its contexts
+  const u32* d_multab = nullptr; u32 multab_W = 0;  // `mul`'s window table in use: one per (device, width), shared by the contexts
+  u32 mul_W_fixed = 0;                         // ecl_hip_set_mul_window: 0 = automatic
+  uint64_t mul_seen = 0;                       // scalars this context has multiplied (never reset: the automatic width goes by it)
   void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -1032,57 +1059,70 @@ static int ensure_gtable(ecl_hip* h) {
   return ECL_OK;
 }
 
-// `mul`'s window table (MUL_W bits per window, see k_gtable_rows): built once per device and process, shared by every
-// context on that device (the host program runs two per GPU), freed with the last of them.  Before it is handed out,
-// sample slots of every row - first, last, and a fixed pseudo-random set - are compared with the double-and-add kernel.
+// `mul`'s window tables (see k_gtable_rows): built once per (device, width) and process, shared by every context on that
+// device that uses the width (the host program runs two per GPU), freed with the last of them.  Before a table is handed
+// out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
+// are compared with the double-and-add kernel.
+#define MUL_W_MIN 8u
+#define MUL_W_MAX 24u
+#define MUL_W_START 18u               /* 14 rows x 2^18 points, 252 MB: built in a few ms */
+#define MUL_W_LONG 22u                /* 12 rows x 2^22 points, 3.0 GB: ~50 ms */
+#define MUL_LONG_AFTER (1ull << 29)   /* scalars a context has seen before it moves to MUL_W_LONG: at 842 vs 919 M scalars/s the
+                                         wider table gains 0.1 ns per scalar, so its build is paid back after 5 * 10^8 of them */
 struct multab_t {
   u32* d = nullptr;
   int refs = 0;
 };
 static std::mutex g_multab_mu;
-static std::map<int, multab_t> g_multab;
+static std::map<std::pair<int, u32>, multab_t> g_multab;
 
 static void release_multable(ecl_hip* h) {
   if (!h->d_multab) return;
   std::lock_guard<std::mutex> lk(g_multab_mu);
-  multab_t& t = g_multab[h->dev];
+  multab_t& t = g_multab[{h->dev, h->multab_W}];
   if (--t.refs == 0) (void)hipFree(t.d), t.d = nullptr;
-  h->d_multab = nullptr;
+  h->d_multab = nullptr, h->multab_W = 0;
 }
 
-static int build_multable(ecl_hip* h, u32** out) {
-  static_assert(MUL_W >= 8 && MUL_W <= 24, "window width");
+static int build_multable(ecl_hip* h, u32 W, u32** out) {
   dbuf<u32> lad_k, lad, tmp, tab, got, want, want_k;
   dbuf<u64> slots;
+  const wtab tb = wtab_make(nullptr, W);
   // ladders: 2^j * 2^(W w) * G for j < the row's digit width
-  std::vector<u32> ks((size_t)MUL_WINDOWS * 32 * 8, 0);
-  for (u32 w = 0; w < MUL_WINDOWS; ++w)
-    for (u32 j = 0; j < 32 && MUL_W * w + j < 256; ++j) words_of(&ks[((size_t)w * 32 + j) * 8], sc_pow2(MUL_W * w + j));
-  const u32 nlad = MUL_WINDOWS * 32;
+  std::vector<u32> ks((size_t)tb.nwin * 32 * 8, 0);
+  for (u32 w = 0; w < tb.nwin; ++w)
+    for (u32 j = 0; j < W && W * w + j < 256; ++j) words_of(&ks[((size_t)w * 32 + j) * 8], sc_pow2(W * w + j));
+  const u32 nlad = tb.nwin * 32;
   HIPCHK(h, hipMalloc(&lad_k.p, ks.size() * sizeof(u32)));
   HIPCHK(h, hipMalloc(&lad.p, (size_t)nlad * 16 * sizeof(u32)));
   HIPCHK(h, hipMemcpyAsync(lad_k.p, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_mul_g, dim3((nlad + 63) / 64), dim3(64), 0, h->stream, lad_k.p, lad.p, (u8*)nullptr, nlad);
   HIPCHK(h, hipGetLastError());
-  const u32 nt = (MUL_PER + 15u) / 16u;
-  HIPCHK(h, hipMalloc(&tmp.p, (size_t)MUL_WINDOWS * 16 * 36 * nt * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&tab.p, MUL_SLOTS * 16 * sizeof(u32)));
-  hipLaunchKernelGGL(k_gtable_rows, dim3((nt + 255) / 256, MUL_WINDOWS), dim3(256), 0, h->stream, lad.p, tab.p, tmp.p, nt);
+  // rows: launches of ~2^18 threads (one thread per 16 entries), the parking space of one launch reused by the next
+  const u32 nt = (tb.per + 15u) / 16u;
+  u32 rows = (1u << 18) / nt;
+  rows = rows < 1 ? 1 : (rows > tb.nwin ? tb.nwin : rows);
+  HIPCHK(h, hipMalloc(&tmp.p, (size_t)rows * 16 * 36 * nt * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&tab.p, wtab_slots(tb) * 16 * sizeof(u32)));
+  for (u32 w0 = 0; w0 < tb.nwin; w0 += rows) {
+    const u32 ny = tb.nwin - w0 < rows ? tb.nwin - w0 : rows;
+    hipLaunchKernelGGL(k_gtable_rows, dim3((nt + 255) / 256, ny), dim3(256), 0, h->stream, lad.p, tab.p, tmp.p, nt, W, w0);
+  }
   HIPCHK(h, hipGetLastError());
   // the check
   const u32 PERW = 48;
   std::vector<u64> sl;
   std::vector<u32> wk;
   u64 z = 0xD1B54A32D192ED03ull;
-  for (u32 w = 0; w < MUL_WINDOWS; ++w) {
-    const u32 count = w == MUL_WINDOWS - 1u ? MUL_TOP_PER : MUL_PER;
+  for (u32 w = 0; w < tb.nwin; ++w) {
+    const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
     for (u32 i = 0; i < PERW; ++i) {
       z ^= z << 13, z ^= z >> 7, z ^= z << 17;
       const u32 b = i == 0 ? 1u : i == 1 ? count : i < 18 ? (i - 1u) : i < 34 ? (i - 17u) * 16u + (i & 1u) : (u32)(z % count) + 1u;
       const u32 digit = b > count ? count : b;
-      sl.push_back((u64)w * MUL_PER + digit - 1);
+      sl.push_back((u64)w * tb.per + digit - 1);
       u32 kw[8];
-      words_of(kw, sc_mul_u64(sc_pow2(MUL_W * w), digit));
+      words_of(kw, sc_mul_u64(sc_pow2(W * w), digit));
       wk.insert(wk.end(), kw, kw + 8);
     }
   }
@@ -1108,15 +1148,31 @@ static int build_multable(ecl_hip* h, u32** out) {
   return ECL_OK;
 }
 
-static int ensure_multable(ecl_hip* h) {
-  if (h->d_multab) return ECL_OK;
+// the table of width W for this context (drops the one it held if that was another width)
+static int ensure_multable(ecl_hip* h, u32 W) {
+  if (h->d_multab && h->multab_W == W) return ECL_OK;
+  if (h->d_multab) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // kernels of earlier calls may still read the old table
+    release_multable(h);
+  }
   std::lock_guard<std::mutex> lk(g_multab_mu);
-  multab_t& t = g_multab[h->dev];
+  multab_t& t = g_multab[{h->dev, W}];
   if (!t.d) {
-    const int rc = build_multable(h, &t.d);
+    const int rc = build_multable(h, W, &t.d);
     if (rc != ECL_OK) return rc;
   }
-  ++t.refs, h->d_multab = t.d;
+  ++t.refs, h->d_multab = t.d, h->multab_W = W;
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_set_mul_window(ecl_hip* h, uint32_t bits) {
+  if (!h || (bits != 0 && (bits < MUL_W_MIN || bits > MUL_W_MAX))) return ECL_E_ARG;
+  h->mul_W_fixed = bits;
+  return ECL_OK;
+}
+extern "C" int ecl_hip_get_mul_window(ecl_hip* h, uint32_t* bits) {
+  if (!h || !bits) return ECL_E_ARG;
+  *bits = h->multab_W;
   return ECL_OK;
 }
 
@@ -1130,7 +1186,11 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  if ((rc = ensure_multable(h)) != ECL_OK) return rc;
+  // window width: the caller's, or the short table until this context has seen enough scalars to pay for the long one
+  const u32 W = h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER ? MUL_W_LONG : MUL_W_START);
+  if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
+  const wtab gtab = wtab_make(h->d_multab, W);
+  h->mul_seen += n;
   if (!h->copy_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -1206,9 +1266,9 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
     const u32 nt = (m + R - 1) / R;
     dim3 grid((nt + 255) / 256), blk(256);
-    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_multab, a, h->d_multmp, nt, R);
-    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_multab, a, h->d_multmp, nt, R);
-    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, h->d_multab, a, h->d_multmp, nt, R);
+    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
   }

@@ -118,9 +118,21 @@ int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_f
    no counterpart (its per-thread buffers live on the stack, main.c:350-352). */
 int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
 
-/* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index. */
+/* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index.
+   The fixed-base window table of ec_gtable_mul (lib/ecc.c:876-929) is built on the device at a window width sized for
+   HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB): a context starts on 18 bits (14 rows, 252 MB, a few
+   ms) and moves to 22 bits (12 rows, 3.0 GB, ~50 ms: 12 additions per scalar instead of 19) once it has multiplied 2^29
+   scalars, which is when the wider table has paid for its build.  A table is checked against the double-and-add kernel
+   on sample slots before use (ECL_E_SELFTEST on a mismatch), shared between the contexts of a device in the process
+   and freed with the last of them.  Results do not depend on the width. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
+/* Optional: fix the window width of this context's `mul` table (8..24 bits; 0 = automatic, the default) from the next
+   ecl_hip_mul_batch on - a caller that knows it will multiply billions of scalars takes 22 at once.  No reference
+   counterpart other than the compile-time _GTABLE_W (lib/ecc.c:876). */
+int ecl_hip_set_mul_window(ecl_hip *h, uint32_t bits);
+/* ... and the width of the table the context holds right now (0: none yet). */
+int ecl_hip_get_mul_window(ecl_hip *h, uint32_t *bits);
 
 /* pk_verify_hash (main.c:248-263) for n reported private keys in one go: both hash160 values of k*G, derived on the
    device by a path other than the walk kernel (fixed-base window sum + own inversion per key).  The window sum and its

@@ -298,6 +298,92 @@ def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
         assert list(h33[i]) == orc.hash160(*orc.point_of(k), True)
 
 
+def _mul_all_against_double_and_add(d, K):
+    """every scalar of K through ecl_hip_mul_batch (all-ones filter) == double-and-add kernel + hash kernel; -> hits"""
+    import ctypes as C
+    from ecloop_amd import capi
+    n = len(K)
+    out = np.zeros(n, dtype=capi.FOUND_DTYPE)
+    cnt = C.c_uint32()
+    assert d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt)) == 0
+    X, Y = np.zeros_like(K), np.zeros_like(K)
+    ok = np.zeros(n, dtype=np.uint8)
+    h33 = np.zeros((n, 5), dtype=np.uint32)
+    h65 = np.zeros((n, 5), dtype=np.uint32)
+    assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
+    assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
+    recs = out[: cnt.value]
+    order = np.argsort(recs["key_offset"])
+    want = np.nonzero(ok)[0]
+    assert np.array_equal(recs["key_offset"][order], want.astype(np.uint64))
+    assert np.array_equal(recs["h160"][order], h33[want])
+    return cnt.value
+
+
+def _digit_edge_scalars(rng, n, W):
+    """random 256-bit scalars plus the digit patterns a W-bit window table can get wrong: every digit at its maximum,
+    a single digit per window (1 and the maximum, the last window's narrower maximum included), 2^256 - 1, n - 1"""
+    K = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, (n, 4), dtype=np.int64).astype(np.uint64)
+    special = [(1 << 256) - 1, orc.N - 1, orc.N + 1, 1, 2]
+    nwin = (256 + W - 1) // W
+    for w in range(nwin):
+        width = min(W, 256 - W * w)
+        special += [1 << (W * w), ((1 << width) - 1) << (W * w), (((1 << width) - 1) << (W * w)) | 1]
+    for i, v in enumerate(special):
+        K[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    return K
+
+
+@pytest.mark.parametrize("W", [8, 13, 14, 16, 18, 20, 22, 24])
+def test_mul_every_window_width_against_double_and_add(W):
+    """the window width of `mul`'s table is a run-time choice (ecl_hip_set_mul_window; the reference's is the compile-time
+    _GTABLE_W = 14, lib/ecc.c:876): results must not depend on it.  Widths that divide 256 and widths that leave a
+    narrower last window, the table built by k_gtable_rows in one launch (small widths) and row group by row group."""
+    from ecloop_amd import Device
+    n = 1 << 16
+    K = _digit_edge_scalars(np.random.default_rng(W), n, W)
+    d = Device(0)
+    try:
+        d.set_bloom(ONES)
+        d.set_mul_window(W)
+        assert _mul_all_against_double_and_add(d, K) == n and d.mul_window() == W
+        with pytest.raises(Exception):
+            d.set_mul_window(25)
+        with pytest.raises(Exception):
+            d.set_mul_window(7)
+    finally:
+        d.close()
+
+
+def test_mul_moves_to_the_long_table_after_2_pow_29_scalars_with_identical_results():
+    """automatic width: 18 bits until the context has seen 2^29 scalars, 22 bits from then on (the call that crosses the
+    line already runs on the long table); two contexts on the device share each table; same hits before and after"""
+    import ctypes as C
+    from ecloop_amd import Device, capi
+    n = 1 << 22
+    K = _digit_edge_scalars(np.random.default_rng(29), n, 22)
+    r = np.random.default_rng(7).integers(0, 1 << 63, (2, 1 << 10), dtype=np.int64).astype(np.uint64)
+    flt = (r[0] | r[1]) << np.uint64(1) | np.uint64(1)  # density ~0.75: 0.75^20 of the hashes pass, ~10^4 hits per call
+    d, d2 = Device(0), Device(0)
+    try:
+        hits = []
+        for dev in (d, d2):
+            dev.set_bloom(flt)
+        out = np.zeros(1 << 16, dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        for call in range(130):  # 130 * 2^22 > 2^29
+            dev = d if call != 64 else d2  # the second context stays on the short table
+            assert dev.lib.ecl_hip_mul_batch(dev.h, K.ctypes.data, n, out.ctypes.data, len(out), C.byref(cnt)) == 0
+            assert dev.mul_window() == (22 if dev is d and call >= 128 else 18)  # d's 128th call (call 64 went to d2) completes 2^29
+            if call in (0, 64, 126, 127, 128, 129):
+                r = out[: cnt.value]
+                hits.append(sorted(zip(r["key_offset"].tolist(), map(tuple, r["h160"].tolist()))))
+        assert len(hits[0]) > 100 and all(h == hits[0] for h in hits)
+    finally:
+        d.close()
+        d2.close()
+
+
 @pytest.mark.parametrize("n", [(1 << 19) - 1, (1 << 20) - 3, (1 << 20) - 1, (1 << 21) - 1])
 def test_mul_batch_sizes_just_below_a_power_of_two(n):
     """ecl_hip_mul_batch with n one to three below 2^19 / 2^20 / 2^21 on a FRESH context: the scalars-per-thread count R

@@ -2,7 +2,7 @@
 """`mul` path throughput (BASELINE.json configs[4]): seeded 256-bit scalars through ecl_hip_mul_batch from a page-locked
 array (host -> device copy of the scalars included), addr33 + addr65, list filter of the brainwallet hashes.  Prints the
 wall rate of each call and the device-side rate (HIP events over the copies + kernels of the call); the first call
-includes building the window table.  ECLOOP_HIP_LIB selects an A/B build (tools/sweep_mul_w.sh: -DMUL_W=...)."""
+includes building the window table.  usage: bench_mul.py [log2 n] [calls] [window bits, 0 = automatic]"""
 import ctypes as C
 import os
 import sys
@@ -17,9 +17,11 @@ from ecloop_amd.engine import load_filter  # noqa: E402
 
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+window = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # 0 = the library's automatic choice
 flt = load_filter(os.path.join(ROOT, "tests", "golden", "btc-bw-hash"))
 d = capi.Device(0, a33=True, a65=True)
 d.set_bloom(flt.words)
+d.set_mul_window(window)
 rng = np.random.RandomState(1)
 ptr = d.lib.ecl_hip_alloc_host(n * 32)
 assert ptr
@@ -34,6 +36,6 @@ for it in range(calls):
     dt = time.perf_counter() - t0
     assert rc == 0
     ms = d.mul_timing()[0]
-    print(f"mul_batch: {n} scalars, a33+a65: wall {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M/s; device {ms-prev:.2f} ms -> {n/(ms-prev)/1e3:.1f} M/s (hits {cnt.value})")
+    print(f"mul_batch: {n} scalars, a33+a65: wall {dt*1e3:.1f} ms -> {n/dt/1e6:.1f} M/s; device {ms-prev:.2f} ms -> {n/(ms-prev)/1e3:.1f} M/s (hits {cnt.value}, window {d.mul_window()} bits)")
     prev = ms
 d.lib.ecl_hip_free_host(ptr)
