@@ -1176,6 +1176,53 @@ extern "C" int ecl_hip_get_mul_window(ecl_hip* h, uint32_t* bits) {
   return ECL_OK;
 }
 
+// what a mul_batch of n scalars needs before its first copy: the window table of the width in force, the copy stream and
+// its events, the device staging for one chunk (x2: the copy engine runs one chunk ahead of the kernel) and the parking
+// space of one chunk - sized to the call, grown on demand
+static int mul_setup(ecl_hip* h, u32 n, u32 W) {
+  int rc;
+  if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
+  if (!h->copy_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+    }
+  }
+  u32 want = 1u << 16;
+  while (want < MUL_CHUNK && want < n) want <<= 1;
+  if (want > h->kbuf_cap) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    for (int i = 0; i < 2; ++i) {
+      if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
+      if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
+      h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
+    }
+    h->pin_cap = 0;
+    if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
+    h->d_multmp = nullptr, h->kbuf_cap = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
+    // the kernel indexes the planes as r * 36 * nt + plane * nt + t with R * nt = m rounded up to a multiple of R:
+    // up to R - 1 slots more than m, so the buffer carries MUL_R spare slots
+    HIPCHK(h, hipMalloc(&h->d_multmp, ((size_t)want + MUL_R) * 36 * sizeof(u32)));
+    h->kbuf_cap = want;
+  }
+  return ECL_OK;
+}
+// window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
+static u32 mul_window_for(const ecl_hip* h, u32 n) {
+  return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER ? MUL_W_LONG : MUL_W_START);
+}
+
+extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
+  if (!h || n == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = ensure_found(h, raw_cap_of(h, cap ? cap : 1) + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  return mul_setup(h, n, mul_window_for(h, n));
+}
+
 extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
   if (!h || (!scalars && n) || (!out && cap) || !nout) return ECL_E_ARG;
@@ -1186,40 +1233,10 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  // window width: the caller's, or the short table until this context has seen enough scalars to pay for the long one
-  const u32 W = h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER ? MUL_W_LONG : MUL_W_START);
-  if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
+  const u32 W = mul_window_for(h, n);
+  if ((rc = mul_setup(h, n, W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
   h->mul_seen += n;
-  if (!h->copy_stream) {
-    HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
-    }
-  }
-  {
-    // staging for one chunk (x2: the copy engine runs one chunk ahead of the kernel): sized to the call, grown on demand
-    u32 want = 1u << 16;
-    while (want < MUL_CHUNK && want < n) want <<= 1;
-    if (want > h->kbuf_cap) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-      for (int i = 0; i < 2; ++i) {
-        if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
-        if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
-        h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
-      }
-      h->pin_cap = 0;
-      if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
-      h->d_multmp = nullptr, h->kbuf_cap = 0;
-      for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
-      // the kernel indexes the planes as r * 36 * nt + plane * nt + t with R * nt = m rounded up to a multiple of R:
-      // up to R - 1 slots more than m, so the buffer carries MUL_R spare slots
-      HIPCHK(h, hipMalloc(&h->d_multmp, ((size_t)want + MUL_R) * 36 * sizeof(u32)));
-      h->kbuf_cap = want;
-    }
-  }
   // Scalars in page-locked host memory (ecl_hip_alloc_host / ecl_hip_pin_host) go to the device by DMA straight from the
   // caller's array; pageable ones are first copied into two pinned staging buffers - a single-threaded memcpy that caps
   // the call near 18 GB/s = 570 M scalars/s (measured), below what the kernel takes.

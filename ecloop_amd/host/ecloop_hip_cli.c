@@ -755,6 +755,27 @@ static void *pack_worker(void *arg) {
   memcpy(s->dst, s->tmp, s->count * 32);
   return NULL;
 }
+/* The normal input - every line 64 hex digits and a newline - needs no line search, no scratch and no packing: record r of
+   the chunk is at byte 65 r and its scalar goes to slot r of the chunk's array.  A slice that meets anything else (another
+   length, a character that is not a hex digit, '\r') reports it and the chunk is parsed the general way. */
+#define MUL_RECORD 65u
+typedef struct { const char *buf; size_t first, last; u64 (*dst)[4]; bool ok; } fixed_slice; /* records [first, last) */
+static void *parse_fixed_worker(void *arg) {
+  fixed_slice *s = arg;
+  s->ok = false;
+#if defined(__x86_64__)
+  for (size_t r = s->first; r < s->last; ++r) {
+    const char *p = s->buf + r * MUL_RECORD;
+    sc k;
+    if (p[64] != '\n' || !hex16_ssse3(p, &k.w[3]) || !hex16_ssse3(p + 16, &k.w[2]) || !hex16_ssse3(p + 32, &k.w[1]) || !hex16_ssse3(p + 48, &k.w[0]))
+      return NULL;
+    k = sc_reduce(k);
+    memcpy(s->dst[r], k.w, 32);
+  }
+  s->ok = true;
+#endif
+  return NULL;
+}
 
 /* a pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n on the workers and
    returns when all are done (64 MB chunks come every few milliseconds; creating 2 x 32 threads for each cost a quarter
@@ -917,6 +938,22 @@ static void ks_grow(const run_t *run, scalar_array *ar, size_t n) {
   if (!ar->ks) ar->ks = malloc(cap * 32);
   ar->cap = cap;
 }
+/* The arrays of a run are allocated while the devices come up (bring_up starts mul_prealloc beside the device threads):
+   page-locking costs 0.3 ms per MB - 45 ms for the four 33 MB arrays of a one-GPU text run, 90 ms with -bin - which the
+   first chunks otherwise wait for one after the other. */
+static scalar_array mul_ready_arrays[MUL_MAX_ARRAYS];
+static int mul_ready_count;
+typedef struct { const run_t *run; int narr; } mul_prealloc_arg;
+static void *mul_prealloc(void *arg) {
+  const mul_prealloc_arg *a = arg;
+  const size_t per = a->run->bin ? MUL_TEXT_CHUNK / 32 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
+  for (int i = 0; i < a->narr && i < MUL_MAX_ARRAYS; ++i) {
+    scalar_array ar = {NULL, 0, 0, false};
+    ks_grow(a->run, &ar, per);
+    mul_ready_arrays[i] = ar, mul_ready_count = i + 1;
+  }
+  return NULL;
+}
 typedef struct {
   run_t *run;
   scalar_array arr[MUL_MAX_ARRAYS];
@@ -941,7 +978,9 @@ static void *mul_device_worker(void *arg) {
     pthread_mutex_unlock(&q->mu);
     scalar_array *ar = &q->arr[i];
     if (q->run->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
-      for (size_t k = 0; k < ar->n; ++k)
+      static int quiet = -1; /* ECLOOP_HIP_PARSE_QUIET=1: the front end alone, nothing printed (timing) */
+      if (quiet < 0) { const char *e = getenv("ECLOOP_HIP_PARSE_QUIET"); quiet = e && e[0] == '1'; }
+      for (size_t k = 0; k < ar->n && !quiet; ++k)
         printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)ar->ks[k][3], (unsigned long long)ar->ks[k][2],
                (unsigned long long)ar->ks[k][1], (unsigned long long)ar->ks[k][0]);
     } else
@@ -952,6 +991,22 @@ static void *mul_device_worker(void *arg) {
     pthread_mutex_unlock(&q->mu);
   }
   return NULL;
+}
+/* a text chunk made of fixed records only -> its array, in place; false: not such a chunk (the array's content is then undefined) */
+static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_chunk *c, scalar_array *ar, u64 *t_grow, u64 *t_parse, u64 *t_mark) {
+  if (run->opt.raw || !have_ssse3 || !c->len || c->len % MUL_RECORD) return false;
+  const size_t nrec = c->len / MUL_RECORD, per = (nrec + (size_t)P - 1) / (size_t)P;
+  ks_grow(run, ar, nrec);
+  *t_grow += us_now() - *t_mark, *t_mark = us_now();
+  fixed_slice fs[32];
+  int nf = 0;
+  for (size_t at = 0; at < nrec; at += per, ++nf) fs[nf] = (fixed_slice){c->buf, at, at + per < nrec ? at + per : nrec, ar->ks, false};
+  pool_run(pool, parse_fixed_worker, fs, sizeof fs[0], nf);
+  bool all = true;
+  for (int i = 0; i < nf; ++i) all = all && fs[i].ok;
+  *t_parse += us_now() - *t_mark, *t_mark = us_now();
+  if (all) ar->n = nrec;
+  return all;
 }
 static void cmd_mul(run_t *run) {
   report_restart_clock(&run->rep);
@@ -971,6 +1026,7 @@ static void cmd_mul(run_t *run) {
   sq.run = run, sq.narr = run->ngpus + 2;
   pthread_mutex_init(&sq.mu, NULL), pthread_cond_init(&sq.cv, NULL);
   for (int i = 0; i < sq.narr; ++i) sq.idle[sq.nidle++] = i;
+  for (int i = 0; i < mul_ready_count && i < sq.narr; ++i) sq.arr[i] = mul_ready_arrays[i]; /* allocated during bring-up */
   pthread_t reader, devth[MAX_GPUS];
   mul_dev_arg dargs[MAX_GPUS];
   pthread_create(&reader, NULL, mul_reader, &tq);
@@ -979,27 +1035,35 @@ static void cmd_mul(run_t *run) {
   memset(sl, 0, sizeof sl);
   pool_t pool;
   pool_init(&pool, P);
+  u64 t_text = 0, t_array = 0, t_parse = 0, t_grow = 0, t_pack = 0, nchunks = 0, nfixed = 0, t_mark; /* us per stage (ECLOOP_HIP_STATS) */
   for (;;) {
+    t_mark = us_now();
     pthread_mutex_lock(&tq.mu);
     while (!tq.count && !tq.eof) pthread_cond_wait(&tq.cv, &tq.mu);
     if (!tq.count) { pthread_mutex_unlock(&tq.mu); break; }
     text_chunk *c = &tq.ring[tq.tail];
     pthread_mutex_unlock(&tq.mu);
+    t_text += us_now() - t_mark, t_mark = us_now(), nchunks++;
     /* an array for this chunk's scalars */
     pthread_mutex_lock(&sq.mu);
     while (!sq.nidle) pthread_cond_wait(&sq.cv, &sq.mu);
     int ai = sq.idle[--sq.nidle];
     pthread_mutex_unlock(&sq.mu);
+    t_array += us_now() - t_mark, t_mark = us_now();
     scalar_array *ar = &sq.arr[ai];
     if (run->bin) { /* the scalars as they are: into the page-locked array, P threads copying */
       ar->n = c->len / 32;
       ks_grow(run, ar, ar->n);
+      t_grow += us_now() - t_mark, t_mark = us_now();
       copy_task ct[32];
       size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
       int nc = 0;
       for (size_t at = 0; at < ar->n; at += per, ++nc)
         ct[nc] = (copy_task){ar->ks + at, c->buf + at * 32, (ar->n - at < per ? ar->n - at : per) * 32};
       pool_run(&pool, copy_worker, ct, sizeof ct[0], nc);
+      t_parse += us_now() - t_mark;
+    } else if (parse_fixed_chunk(run, &pool, P, c, ar, &t_grow, &t_parse, &t_mark)) {
+      nfixed++; /* every line was 64 hex digits + newline: parsed in place */
     } else {
       int ns = 0;
       size_t at = 0, end = c->len;
@@ -1011,13 +1075,16 @@ static void cmd_mul(run_t *run) {
         at = stop, ns++;
       }
       pool_run(&pool, parse_worker, sl, sizeof sl[0], ns);
+      t_parse += us_now() - t_mark, t_mark = us_now();
       size_t total = 0;
       for (int i = 0; i < ns; ++i) total += sl[i].count;
       ks_grow(run, ar, total);
+      t_grow += us_now() - t_mark, t_mark = us_now();
       ar->n = total;
       size_t off = 0;
       for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count;
       pool_run(&pool, pack_worker, sl, sizeof sl[0], ns);
+      t_pack += us_now() - t_mark;
     }
     pthread_mutex_lock(&tq.mu); /* the text buffer goes back to the reader */
     tq.tail = (tq.tail + 1) % MUL_TEXT_RING, tq.count--;
@@ -1039,6 +1106,10 @@ static void cmd_mul(run_t *run) {
   for (int i = 0; i < sq.narr; ++i) ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
   for (int i = 0; i < 32; ++i) free(sl[i].tmp);
   if (!run->parse_only) report_close(&run->rep);
+  if (getenv("ECLOOP_HIP_STATS")) /* where the front end's wall time went (the main thread drives one chunk at a time) */
+    fprintf(stderr, "mul front end: %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, waiting for a free array (devices behind) %.1f, "
+            "parse / copy %.1f, array growth %.1f, pack %.1f\n", (unsigned long long)nchunks, (unsigned long long)nfixed, P, t_text / 1e3, t_array / 1e3, t_parse / 1e3,
+            t_grow / 1e3, t_pack / 1e3);
 }
 
 /* ------------------------------------------------------------------------------------------- rnd */
@@ -1396,6 +1467,10 @@ static void *bringup_thread(void *arg) {
   if (rc == ECL_OK && run->flt.list) rc = ecl_hip_set_list(*h, (const uint32_t(*)[5])run->flt.list, run->flt.nlist);
   b->t[3] = us_now();
   if (rc == ECL_OK && b->reserve_keys) rc = ecl_hip_reserve(*h, b->reserve_keys, 4096);
+  if (rc == ECL_OK && run->cmd == CMD_MUL && !run->parse_only) { /* window table, staging and record buffer of a usual batch (mul_flush's sizes) */
+    const u32 n = (u32)(run->bin ? MUL_TEXT_CHUNK / 32 : MUL_TEXT_CHUNK / MUL_RECORD + 1024);
+    rc = ecl_hip_reserve_mul(*h, n, n * 2 + 16);
+  }
   b->t[4] = us_now();
   b->rc = rc;
   return NULL;
@@ -1425,7 +1500,11 @@ static double bring_up(run_t *run, int shown, int real) {
     job[g] = (bringup_t){run, g, dev_of[g], flags, largest_call, ECL_OK, {0}};
     pthread_create(&th[g], NULL, bringup_thread, &job[g]);
   }
+  pthread_t pre;
+  mul_prealloc_arg prea = {run, run->ngpus + 2};
+  const bool prealloc = run->cmd == CMD_MUL && !run->parse_only && pthread_create(&pre, NULL, mul_prealloc, &prea) == 0;
   for (int g = 0; g < run->ngpus; ++g) pthread_join(th[g], NULL);
+  if (prealloc) pthread_join(pre, NULL);
   for (int g = 0; g < run->ngpus; ++g)
     if (job[g].rc != ECL_OK) die_ecl(run, g, job[g].rc, "open");
   if (getenv("ECLOOP_HIP_STATS"))

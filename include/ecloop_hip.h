@@ -127,6 +127,11 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
    and freed with the last of them.  Results do not depend on the width. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
+/* Optional: set up now what a later ecl_hip_mul_batch of up to n scalars with record capacity `cap` needs (the window
+   table of the width in force, device staging, record buffer), so that the first batch does not pay for it - the
+   counterpart of ecl_hip_reserve for `mul`; the reference builds its table at the start of cmd_mul (main.c:543). */
+int ecl_hip_reserve_mul(ecl_hip *h, uint32_t n, uint32_t cap);
+
 /* Optional: fix the window width of this context's `mul` table (8..24 bits; 0 = automatic, the default) from the next
    ecl_hip_mul_batch on - a caller that knows it will multiply billions of scalars takes 22 at once.  No reference
    counterpart other than the compile-time _GTABLE_W (lib/ecc.c:876). */

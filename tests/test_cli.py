@@ -374,6 +374,26 @@ def test_mul_parser_hex_lines_match_fe_modn_from_hex(cli):
     assert _parse(cli, ("\r\n".join(lines)).encode()) == want  # CRLF, no newline at the end
 
 
+def test_mul_parser_fixed_record_path_and_its_fallback(cli):
+    """a chunk made only of 64-hex-digit lines is parsed in place (record r at byte 65 r); ONE line of the same length
+    with a character that is not a hex digit, or a missing final newline, sends the chunk through the general parser -
+    same scalars either way (fe_modn_from_hex skips the junk character, lib/ecc.c:81-95)"""
+    import random
+    import orc
+    r = random.Random(11)
+    lines = [("%064x" % r.getrandbits(256)) if i % 3 else ("%064X" % r.getrandbits(256)) for i in range(40000)]
+    lines[7] = "%064x" % (orc.N + 1)
+    want = ["%064x" % orc.sn_from_hex(l) for l in lines]
+    assert _parse(cli, ("\n".join(lines) + "\n").encode()) == want       # fixed path
+    assert _parse(cli, ("\n".join(lines)).encode()) == want              # no final newline: general path
+    bad = list(lines)
+    bad[23456] = bad[23456][:10] + "z" + bad[23456][11:]                  # still 64 characters
+    bad[39999] = " " + bad[39999][1:]
+    assert _parse(cli, ("\n".join(bad) + "\n").encode()) == ["%064x" % orc.sn_from_hex(l) for l in bad]
+    crlf = ("\r\n".join(lines[:1000]) + "\r\n").encode()                 # 66-byte records
+    assert _parse(cli, crlf) == want[:1000]
+
+
 def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
     """-raw = SHA-256 of the line (main.c:505-527) for lengths around the padding boundaries; -bin passes 32-byte
     little-endian scalars through; an input of several 64 MB chunks keeps every line, in order"""

@@ -19,9 +19,10 @@ for mode in txt bin; do
   flag=""; [ $mode = bin ] && flag="-bin"
   for rep in 1 2; do
     t0=$(date +%s.%N)
-    "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>/tmp/mul_err.txt >/dev/null
+    ECLOOP_HIP_STATS=1 "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>/tmp/mul_err.txt >/dev/null
     t1=$(date +%s.%N)
     st=$(tr '\r' '\n' < /tmp/mul_err.txt | grep Mkeys | tail -1)
+    tr "\r" "\n" < /tmp/mul_err.txt | grep -E "front end|setup|mul:" | sed "s/^/      /"
     echo "$mode run $rep, $N scalars: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s (process start-up and GPU bring-up included) | status line: $st"
   done
 done
