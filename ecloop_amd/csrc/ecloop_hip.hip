@@ -500,6 +500,7 @@ struct ecl_hip {
   const u32* d_multab = nullptr; u32 multab_W = 0;  // `mul`'s window table in use: one per (device, width), shared by the contexts
   u32 mul_W_fixed = 0;                         // ecl_hip_set_mul_window: 0 = automatic
   uint64_t mul_seen = 0;                       // scalars this context has multiplied (never reset: the automatic width goes by it)
+  bool mul_long_failed = false;                // the long table could not be allocated: do not try again
   void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -1212,7 +1213,7 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
 }
 // window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
 static u32 mul_window_for(const ecl_hip* h, u32 n) {
-  return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER ? MUL_W_LONG : MUL_W_START);
+  return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER && !h->mul_long_failed ? MUL_W_LONG : MUL_W_START);
 }
 
 extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
@@ -1233,8 +1234,14 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  const u32 W = mul_window_for(h, n);
-  if ((rc = mul_setup(h, n, W)) != ECL_OK) return rc;
+  u32 W = mul_window_for(h, n);
+  rc = mul_setup(h, n, W);
+  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {  // no room for the long table (3.6 GB while it is built): stay on the short one
+    (void)hipGetLastError();
+    h->mul_long_failed = true, W = MUL_W_START;
+    rc = mul_setup(h, n, W);
+  }
+  if (rc != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
   h->mul_seen += n;
   // Scalars in page-locked host memory (ecl_hip_alloc_host / ecl_hip_pin_host) go to the device by DMA straight from the

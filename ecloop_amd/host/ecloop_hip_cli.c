@@ -19,6 +19,7 @@
 #include <locale.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <signal.h>
 #include <stdbool.h>
 #include <stddef.h>
@@ -609,31 +610,86 @@ static void cmd_add(run_t *run) {
 
 /* ------------------------------------------------------------------------------------------- mul */
 /* host SHA-256 of a passphrase for `-raw` (main.c:505-527): input preparation, not the search path.  Block by block,
-   nothing allocated per line. */
-static void sha256_block(u32 st[8], const u8 *blk) {
-  static const u32 K[64] = {
-      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
-      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
-      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
-      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
-      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+   nothing allocated per line.  With the x86 SHA extensions (every EPYC, Xeons since Ice Lake) a block is 64 rounds in 32
+   `sha256rnds2`; elsewhere the plain form with the eight working variables renamed instead of moved. */
+static const u32 SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static void sha256_block_plain(u32 st[8], const u8 *blk) {
 #define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
-  u32 w[64], v[8];
+#define SHA_ROUND(a, b, c, d, e, f, g, h, i)                                                                      \
+  do {                                                                                                            \
+    u32 t1 = (h) + (ROR(e, 6) ^ ROR(e, 11) ^ ROR(e, 25)) + (((e) & (f)) ^ (~(e) & (g))) + SHA_K[i] + w[i];        \
+    u32 t2 = (ROR(a, 2) ^ ROR(a, 13) ^ ROR(a, 22)) + (((a) & (b)) ^ ((a) & (c)) ^ ((b) & (c)));                   \
+    (d) += t1, (h) = t1 + t2;                                                                                     \
+  } while (0)
+  u32 w[64];
   for (int i = 0; i < 16; ++i) w[i] = (u32)blk[4 * i] << 24 | (u32)blk[4 * i + 1] << 16 | (u32)blk[4 * i + 2] << 8 | blk[4 * i + 3];
   for (int i = 16; i < 64; ++i)
     w[i] = w[i - 16] + (ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
            (ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10));
-  memcpy(v, st, 32);
-  for (int i = 0; i < 64; ++i) {
-    u32 t1 = v[7] + (ROR(v[4], 6) ^ ROR(v[4], 11) ^ ROR(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + K[i] + w[i];
-    u32 t2 = (ROR(v[0], 2) ^ ROR(v[0], 13) ^ ROR(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
-    memmove(v + 1, v, 28);
-    v[4] += t1, v[0] = t1 + t2;
+  u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+  for (int i = 0; i < 64; i += 8) {
+    SHA_ROUND(a, b, c, d, e, f, g, h, i);
+    SHA_ROUND(h, a, b, c, d, e, f, g, i + 1);
+    SHA_ROUND(g, h, a, b, c, d, e, f, i + 2);
+    SHA_ROUND(f, g, h, a, b, c, d, e, i + 3);
+    SHA_ROUND(e, f, g, h, a, b, c, d, i + 4);
+    SHA_ROUND(d, e, f, g, h, a, b, c, i + 5);
+    SHA_ROUND(c, d, e, f, g, h, a, b, i + 6);
+    SHA_ROUND(b, c, d, e, f, g, h, a, i + 7);
   }
-  for (int i = 0; i < 8; ++i) st[i] += v[i];
+  st[0] += a, st[1] += b, st[2] += c, st[3] += d, st[4] += e, st[5] += f, st[6] += g, st[7] += h;
+#undef SHA_ROUND
 #undef ROR
+}
+#if defined(__x86_64__)
+#include <cpuid.h>
+#include <immintrin.h>
+__attribute__((target("sha,sse4.1,ssse3"))) static void sha256_block_ni(u32 st[8], const u8 *blk) {
+  const __m128i swap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL); /* big-endian words */
+  __m128i t = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&st[0]), 0xB1);       /* c d a b */
+  __m128i s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&st[4]), 0x1B);      /* e f g h, reversed */
+  __m128i s0 = _mm_alignr_epi8(t, s1, 8);                                              /* the unit's operand order: a b e f */
+  s1 = _mm_blend_epi16(s1, t, 0xF0);                                                   /* c d g h */
+  const __m128i keep0 = s0, keep1 = s1;
+  __m128i m[4];
+  for (int i = 0; i < 16; ++i) { /* four rounds per step */
+    if (i < 4) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(blk + 16 * i)), swap);
+    else {
+      __m128i x = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);                /* W[t-16] + s0(W[t-15]) */
+      x = _mm_add_epi32(x, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));  /* + W[t-7] */
+      m[i & 3] = _mm_sha256msg2_epu32(x, m[(i + 3) & 3]);                        /* + s1(W[t-2]) */
+    }
+    __m128i wk = _mm_add_epi32(m[i & 3], _mm_loadu_si128((const __m128i *)&SHA_K[4 * i]));
+    s1 = _mm_sha256rnds2_epu32(s1, s0, wk);
+    s0 = _mm_sha256rnds2_epu32(s0, s1, _mm_shuffle_epi32(wk, 0x0E));
+  }
+  s0 = _mm_add_epi32(s0, keep0), s1 = _mm_add_epi32(s1, keep1);
+  t = _mm_shuffle_epi32(s0, 0x1B);
+  s1 = _mm_shuffle_epi32(s1, 0xB1);
+  _mm_storeu_si128((__m128i *)&st[0], _mm_blend_epi16(t, s1, 0xF0));
+  _mm_storeu_si128((__m128i *)&st[4], _mm_alignr_epi8(s1, t, 8));
+}
+static bool cpu_has_sha(void) {
+  unsigned a, b, c, d;
+  if (getenv("ECLOOP_HIP_NO_SHANI")) return false; /* tests: the plain form on a CPU that has the extension */
+  return __get_cpuid_count(7, 0, &a, &b, &c, &d) && (b & (1u << 29)) && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+}
+#else
+static bool cpu_has_sha(void) { return false; }
+#endif
+static bool have_sha_ni; /* set once in cmd_mul */
+static void sha256_block(u32 st[8], const u8 *blk) {
+#if defined(__x86_64__)
+  if (have_sha_ni) { sha256_block_ni(st, blk); return; }
+#endif
+  sha256_block_plain(st, blk);
 }
 static void sha256_stream(u32 st[8], const u8 *msg, size_t len) {
   static const u32 IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
@@ -777,60 +833,84 @@ static void *parse_fixed_worker(void *arg) {
   return NULL;
 }
 
-/* a pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n on the workers and
-   returns when all are done (64 MB chunks come every few milliseconds; creating 2 x 32 threads for each cost a quarter
-   of the front end's time) */
-typedef struct {
-  pthread_t th[32];
+/* A pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n - task i on worker
+   i mod nth - and returns when all are done.  A 64 MB chunk is ~1 ms of work for 32 threads and they come back to back,
+   so the hand-over must cost microseconds: workers wait for the next generation number spinning (a few hundred
+   microseconds at most, then they sleep on a condition variable until woken), finish by bumping one atomic counter.
+   (Round 2's pool handed tasks out under a mutex and woke everybody through a condition variable: with 32 threads the
+   hand-over cost as much as the parsing, with 64 it was slower than with 16.) */
+#include <stdatomic.h>
+#define MUL_POOL_MAX 128
+typedef struct pool_t pool_t;
+typedef struct { pool_t *pool; int idx; } pool_seat;
+struct pool_t {
+  pthread_t th[MUL_POOL_MAX];
+  pool_seat seat[MUL_POOL_MAX];
   int nth;
   void *(*fn)(void *);
   char *args;
   size_t stride;
-  int n, next, done;
-  u64 gen;
-  bool quit;
+  int n;
+  atomic_ullong gen;
+  atomic_int done, sleepers;
+  atomic_bool quit;
   pthread_mutex_t mu;
-  pthread_cond_t cv_work, cv_done;
-} pool_t;
+  pthread_cond_t cv;
+};
+static inline void cpu_relax(void) {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
 static void *pool_main(void *arg) {
-  pool_t *p = arg;
-  u64 seen = 0;
-  pthread_mutex_lock(&p->mu);
+  pool_seat *me = arg;
+  pool_t *p = me->pool;
+  unsigned long long seen = 0;
   for (;;) {
-    while (!p->quit && (p->gen == seen || p->next >= p->n)) {
-      if (p->gen != seen && p->next >= p->n) seen = p->gen;
-      pthread_cond_wait(&p->cv_work, &p->mu);
+    int spins = 0;
+    while (atomic_load(&p->gen) == seen && !atomic_load(&p->quit)) {
+      if (++spins < 40000) { cpu_relax(); continue; }
+      pthread_mutex_lock(&p->mu);
+      atomic_fetch_add(&p->sleepers, 1);
+      while (atomic_load(&p->gen) == seen && !atomic_load(&p->quit)) pthread_cond_wait(&p->cv, &p->mu);
+      atomic_fetch_sub(&p->sleepers, 1);
+      pthread_mutex_unlock(&p->mu);
     }
-    if (p->quit) break;
-    int i = p->next++;
-    void *(*fn)(void *) = p->fn;
-    void *a = p->args + (size_t)i * p->stride;
-    pthread_mutex_unlock(&p->mu);
-    fn(a);
-    pthread_mutex_lock(&p->mu);
-    if (++p->done == p->n) pthread_cond_signal(&p->cv_done);
+    if (atomic_load(&p->quit)) break;
+    seen = atomic_load(&p->gen);
+    for (int i = me->idx; i < p->n; i += p->nth) p->fn(p->args + (size_t)i * p->stride);
+    atomic_fetch_add(&p->done, 1);
   }
-  pthread_mutex_unlock(&p->mu);
   return NULL;
+}
+static void pool_wake(pool_t *p) {
+  if (atomic_load(&p->sleepers) > 0) {
+    pthread_mutex_lock(&p->mu);
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+  }
 }
 static void pool_init(pool_t *p, int nth) {
   memset(p, 0, sizeof *p);
-  pthread_mutex_init(&p->mu, NULL), pthread_cond_init(&p->cv_work, NULL), pthread_cond_init(&p->cv_done, NULL);
+  pthread_mutex_init(&p->mu, NULL), pthread_cond_init(&p->cv, NULL);
   p->nth = nth;
-  for (int i = 0; i < nth; ++i) pthread_create(&p->th[i], NULL, pool_main, p);
+  for (int i = 0; i < nth; ++i) p->seat[i] = (pool_seat){p, i}, pthread_create(&p->th[i], NULL, pool_main, &p->seat[i]);
 }
 static void pool_run(pool_t *p, void *(*fn)(void *), void *args, size_t stride, int n) {
   if (n <= 0) return;
-  pthread_mutex_lock(&p->mu);
-  p->fn = fn, p->args = args, p->stride = stride, p->n = n, p->next = 0, p->done = 0, p->gen++;
-  pthread_cond_broadcast(&p->cv_work);
-  while (p->done < n) pthread_cond_wait(&p->cv_done, &p->mu);
-  pthread_mutex_unlock(&p->mu);
+  p->fn = fn, p->args = args, p->stride = stride, p->n = n;
+  atomic_store(&p->done, 0);
+  atomic_fetch_add(&p->gen, 1); /* publishes the fields above */
+  pool_wake(p);
+  for (int spins = 0; atomic_load(&p->done) < p->nth; ++spins) {
+    if (spins < 100000) cpu_relax();
+    else sched_yield();
+  }
 }
 static void pool_stop(pool_t *p) {
+  atomic_store(&p->quit, true);
   pthread_mutex_lock(&p->mu);
-  p->quit = true;
-  pthread_cond_broadcast(&p->cv_work);
+  pthread_cond_broadcast(&p->cv);
   pthread_mutex_unlock(&p->mu);
   for (int i = 0; i < p->nth; ++i) pthread_join(p->th[i], NULL);
 }
@@ -842,13 +922,15 @@ static void *copy_worker(void *arg) {
 }
 
 /* text chunks: reader thread -> parser */
-#define MUL_TEXT_CHUNK ((size_t)64 << 20)
+#define MUL_TEXT_CHUNK ((size_t)64 << 20) /* hex lines and -bin: ~1 M / 2 M scalars per chunk */
+#define MUL_RAW_CHUNK ((size_t)16 << 20)  /* -raw: pass phrases are a quarter as long as hex keys - about as many scalars per chunk */
 #define MUL_TEXT_RING 3
 typedef struct { char *buf, *own; size_t len; } text_chunk; /* buf = own (a ring buffer) or a slice of the mapped input */
 typedef struct {
   text_chunk ring[MUL_TEXT_RING];
   int head, tail, count; /* filled chunks: [tail, head) */
   bool eof, bin;
+  size_t chunk; /* bytes per chunk */
   pthread_mutex_t mu;
   pthread_cond_t cv;
 } text_queue;
@@ -863,7 +945,7 @@ static void *mul_reader(void *arg) {
     if (map != MAP_FAILED) {
       madvise(map, size, MADV_SEQUENTIAL);
       for (size_t at = (size_t)pos; at < size;) {
-        size_t end = at + MUL_TEXT_CHUNK < size ? at + MUL_TEXT_CHUNK : size;
+        size_t end = at + q->chunk < size ? at + q->chunk : size;
         if (end < size) {
           if (q->bin) end = at + (end - at) / 32 * 32;
           else {
@@ -888,7 +970,7 @@ static void *mul_reader(void *arg) {
       return NULL; /* the mapping stays until exit: the last chunks are still being parsed */
     }
   }
-  char *carry = malloc(MUL_TEXT_CHUNK);
+  char *carry = malloc(q->chunk);
   size_t have = 0;
   for (;;) {
     pthread_mutex_lock(&q->mu);
@@ -898,8 +980,8 @@ static void *mul_reader(void *arg) {
     c->buf = c->own;
     memcpy(c->buf, carry, have);
     size_t got;
-    while (have < MUL_TEXT_CHUNK && (got = fread(c->buf + have, 1, MUL_TEXT_CHUNK - have, stdin)) > 0) have += got;
-    bool eof = have < MUL_TEXT_CHUNK;
+    while (have < q->chunk && (got = fread(c->buf + have, 1, q->chunk - have, stdin)) > 0) have += got;
+    bool eof = have < q->chunk;
     size_t end = have;
     if (!eof) {
       if (q->bin) end = have / 32 * 32;
@@ -998,7 +1080,7 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
   const size_t nrec = c->len / MUL_RECORD, per = (nrec + (size_t)P - 1) / (size_t)P;
   ks_grow(run, ar, nrec);
   *t_grow += us_now() - *t_mark, *t_mark = us_now();
-  fixed_slice fs[32];
+  fixed_slice fs[MUL_POOL_MAX];
   int nf = 0;
   for (size_t at = 0; at < nrec; at += per, ++nf) fs[nf] = (fixed_slice){c->buf, at, at + per < nrec ? at + per : nrec, ar->ks, false};
   pool_run(pool, parse_fixed_worker, fs, sizeof fs[0], nf);
@@ -1014,13 +1096,20 @@ static void cmd_mul(run_t *run) {
 #if defined(__x86_64__)
   have_ssse3 = __builtin_cpu_supports("ssse3");
 #endif
+  have_sha_ni = cpu_has_sha();
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-  int P = (int)(ncpu < 1 ? 1 : ncpu > 32 ? 32 : ncpu);
+  /* pool size: the main thread and the reader keep a core each (the pool's workers spin).  Hex lines and -bin are bound by
+     getting the input's pages mapped and read, which stops scaling at 16 threads on the 2 x 64-core box (text 2^27 lines:
+     16 threads 636, 32 threads 378, 64 threads 275 M lines/s); -raw is SHA-256 work and takes 32 (174 / 256 / 161) */
+  const int pool_cap = run->opt.raw && !run->bin ? 32 : 16;
+  int P = (int)(ncpu < 3 ? 1 : ncpu > pool_cap + 2 ? pool_cap : ncpu - 2);
+  { const char *e = getenv("ECLOOP_HIP_PARSE_THREADS"); /* experiments */
+    if (e && atoi(e) >= 1 && atoi(e) <= MUL_POOL_MAX) P = atoi(e); }
   text_queue tq;
   memset(&tq, 0, sizeof tq);
-  tq.bin = run->bin;
+  tq.bin = run->bin, tq.chunk = run->opt.raw && !run->bin ? MUL_RAW_CHUNK : MUL_TEXT_CHUNK;
   pthread_mutex_init(&tq.mu, NULL), pthread_cond_init(&tq.cv, NULL);
-  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = malloc(MUL_TEXT_CHUNK);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = malloc(tq.chunk);
   scalar_queue sq;
   memset(&sq, 0, sizeof sq);
   sq.run = run, sq.narr = run->ngpus + 2;
@@ -1031,7 +1120,7 @@ static void cmd_mul(run_t *run) {
   mul_dev_arg dargs[MAX_GPUS];
   pthread_create(&reader, NULL, mul_reader, &tq);
   for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
-  parse_slice sl[32];
+  parse_slice sl[MUL_POOL_MAX];
   memset(sl, 0, sizeof sl);
   pool_t pool;
   pool_init(&pool, P);
@@ -1055,7 +1144,7 @@ static void cmd_mul(run_t *run) {
       ar->n = c->len / 32;
       ks_grow(run, ar, ar->n);
       t_grow += us_now() - t_mark, t_mark = us_now();
-      copy_task ct[32];
+      copy_task ct[MUL_POOL_MAX];
       size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
       int nc = 0;
       for (size_t at = 0; at < ar->n; at += per, ++nc)
@@ -1104,7 +1193,7 @@ static void cmd_mul(run_t *run) {
   for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
   for (int i = 0; i < sq.narr; ++i) ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
-  for (int i = 0; i < 32; ++i) free(sl[i].tmp);
+  for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp);
   if (!run->parse_only) report_close(&run->rep);
   if (getenv("ECLOOP_HIP_STATS")) /* where the front end's wall time went (the main thread drives one chunk at a time) */
     fprintf(stderr, "mul front end: %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, waiting for a free array (devices behind) %.1f, "
