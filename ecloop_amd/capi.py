@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_reserve_mul", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
 ]
 
 _lib = None
@@ -69,6 +69,7 @@ def load():
     lib.ecl_hip_unpin_host.argtypes = [C.c_void_p]
     lib.ecl_hip_set_mul_window.argtypes = [P, C.c_uint32]
     lib.ecl_hip_reserve_mul.argtypes = [P, C.c_uint32, C.c_uint32]
+    lib.ecl_hip_mul_batch_raw.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_mul_window.argtypes = [P, C.POINTER(C.c_uint32)]
     lib.ecl_hip_verify.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ecl_hip_alloc_host.argtypes = [C.c_size_t]
@@ -181,6 +182,21 @@ class Device:
         out = np.zeros(cap, dtype=FOUND_DTYPE)
         n = C.c_uint32()
         rc = self.lib.ecl_hip_mul_batch(self.h, k.ctypes.data, len(k), out.ctypes.data, cap, C.byref(n))
+        self._chk(rc, allow=(E_OVERFLOW,))
+        return out[: min(n.value, cap)], n.value
+
+    def mul_batch_raw(self, lines, cap=4096):
+        """`mul -raw`: lines = list of bytes objects; their SHA-256 digests are the scalars (hashed on the device)"""
+        text = b"".join(lines)
+        table = np.zeros(len(lines), dtype=np.uint64)
+        at = 0
+        for i, l in enumerate(lines):
+            table[i] = at | (len(l) << 32)
+            at += len(l)
+        buf = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(cap, dtype=FOUND_DTYPE)
+        n = C.c_uint32()
+        rc = self.lib.ecl_hip_mul_batch_raw(self.h, buf.ctypes.data, len(text), table.ctypes.data, len(lines), out.ctypes.data, cap, C.byref(n))
         self._chk(rc, allow=(E_OVERFLOW,))
         return out[: min(n.value, cap)], n.value
 

@@ -300,6 +300,45 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
     check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
   }
 }
+// `mul -raw` (main.c:505-527): the scalar of a line is the SHA-256 of its bytes.  One lane per line: the line's bytes are
+// gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and
+// compressed block by block; the digest, read as a big-endian 256-bit number, is written where k_mul_check expects the
+// scalar (8 little-endian words).  lines[i] = start | length << 32, offsets into `text`; `text` carries 8 spare bytes.
+__global__ void __launch_bounds__(256) k_raw_scalars(const u32* __restrict__ text, u32 text_bytes, const u64* __restrict__ lines, u32 n, u32* __restrict__ out,
+                                                      u32* __restrict__ bad) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 ln = lines[i];
+  const u32 start = (u32)ln;
+  u32 L = (u32)(ln >> 32);
+  if ((u64)start + L > text_bytes) *bad = 1, L = 0;  // a line outside the text: the call is refused (ECL_E_ARG), nothing is read there
+  u32 st[8];
+  sha256_init(st);
+  const u32 nblk = (L + 9u + 63u) >> 6;
+#pragma unroll 1
+  for (u32 b = 0; b < nblk; ++b) {
+    u32 w[16];
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) {
+      const u32 pos = 64u * b + 4u * j;
+      u32 v = 0;
+      if (pos < L) {
+        const u32 at = start + pos, sh = (at & 3u) * 8u;
+        const u32 lo = text[at >> 2], hi = text[(at >> 2) + 1];
+        const u32 raw = (u32)((((u64)hi << 32) | lo) >> sh);  // the four bytes at `at`, first byte lowest
+        v = __builtin_bswap32(raw);
+        const u32 have = L - pos;
+        if (have < 4u) v &= ~(0xFFFFFFFFu >> (8u * have));
+      }
+      if (pos <= L && L - pos < 4u) v |= 0x80000000u >> (8u * (L - pos));
+      w[j] = v;
+    }
+    if (b == nblk - 1u) w[14] = L >> 29, w[15] = L << 3;
+    sha256_compress(st, w);
+  }
+  uint4* o = (uint4*)(out + (size_t)i * 8);
+  o[0] = make_uint4(st[7], st[6], st[5], st[4]), o[1] = make_uint4(st[3], st[2], st[1], st[0]);
+}
 // k*G of ONE scalar (kernel argument) through the window table: the base centre of a non-contiguous add call.
 // 19 mixed additions + one inversion (~0.1 ms) instead of the 256-step double-and-add of k_mul_g (~1.2 ms of latency).
 struct scalar_arg { u32 w[8]; };
@@ -502,6 +541,7 @@ struct ecl_hip {
   uint64_t mul_seen = 0;                       // scalars this context has multiplied (never reset: the automatic width goes by it)
   bool mul_long_failed = false;                // the long table could not be allocated: do not try again
   void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
+  u32* d_rawtext = nullptr; size_t rawtext_cap = 0; u64* d_rawlines = nullptr; u32 rawlines_cap = 0;  // `mul -raw`: text and line table of one call
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
@@ -579,7 +619,7 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   HIPCHK(h, hipEventCreate(&h->ev_s1));
   HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&h->d_counter, 2 * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_counter, 4 * sizeof(u32)));  // [0] records appended, [1] records confirmed by the list, [2] bad-input flag of mul_batch_raw
   // the self-test checks the CODE (known answers, walk kernel against the double-and-add kernel): once per process
   // for every (device, kernel selection) is enough - eight handles for eight shards of one scan do not repeat it
   static std::mutex mu;
@@ -611,7 +651,7 @@ void ecl_hip_close(ecl_hip* h) {
     if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-  (void)hipFree(h->d_multmp), (void)hipFree(h->d_ver);
+  (void)hipFree(h->d_multmp), (void)hipFree(h->d_ver), (void)hipFree(h->d_rawtext), (void)hipFree(h->d_rawlines);
   release_multable(h);
   if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
   if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
@@ -1303,6 +1343,90 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));  // copies + kernels of this call, as the stream saw them
+    h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
+  }
+  return rc;
+}
+
+// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests.  One chunk per call (the caller
+// cuts: n <= 2^22 lines); text and line table cross PCIe on the copy stream, hashing and the window sums follow on the
+// context's stream.  Two contexts per GPU overlap one call's copies with the other's kernels, as for ecl_hip_mul_batch.
+extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t text_bytes, const uint64_t* lines, uint32_t n, ecl_found* out,
+                                     uint32_t cap, uint32_t* nout) {
+  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_CHUNK || text_bytes > 0xFFFFFFF0u) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  u32 W = mul_window_for(h, n);
+  rc = mul_setup(h, n, W);
+  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {
+    (void)hipGetLastError();
+    h->mul_long_failed = true, W = MUL_W_START;
+    rc = mul_setup(h, n, W);
+  }
+  if (rc != ECL_OK) return rc;
+  const wtab gtab = wtab_make(h->d_multab, W);
+  h->mul_seen += n;
+  const size_t text_words = ((size_t)text_bytes + 3) / 4 + 2;  // two spare words: the gather reads one word past the last byte
+  if (text_words > h->rawtext_cap || n > h->rawlines_cap) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    if (text_words > h->rawtext_cap) {
+      if (h->d_rawtext) HIPCHK(h, hipFree(h->d_rawtext));
+      h->d_rawtext = nullptr, h->rawtext_cap = 0;
+      size_t capw = (size_t)1 << 22;  // 16 MB of text
+      while (capw < text_words) capw <<= 1;
+      HIPCHK(h, hipMalloc(&h->d_rawtext, capw * 4));
+      HIPCHK(h, hipMemset(h->d_rawtext, 0, capw * 4));
+      h->rawtext_cap = capw;
+    }
+    if (n > h->rawlines_cap) {
+      if (h->d_rawlines) HIPCHK(h, hipFree(h->d_rawlines));
+      h->d_rawlines = nullptr, h->rawlines_cap = 0;
+      u32 capl = 1u << 20;
+      while (capl < n) capl <<= 1;
+      HIPCHK(h, hipMalloc(&h->d_rawlines, (size_t)capl * 8));
+      h->rawlines_cap = capl;
+    }
+  }
+  add_args a;
+  memset(&a, 0, sizeof a);
+  a.bloom = bloom_make(h->d_bloom, h->bloom_words);
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 3 * sizeof(u32), h->stream));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_rawtext, text, text_bytes, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_rawlines, lines, (size_t)n * 8, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
+  hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
+  u32 R = n >> 17;
+  R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
+  const u32 nt = (n + R - 1) / R;
+  dim3 grid((nt + 255) / 256), blk(256);
+  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  u32 cnt = 0;
+  rc = collect_found(h, cap, rcap, out, &cnt, false);
+  *nout = cnt;
+  u32 bad = 0;
+  HIPCHK(h, hipMemcpy(&bad, h->d_counter + 2, sizeof bad, hipMemcpyDeviceToHost));
+  if (bad) {
+    h->err = "mul_batch_raw: a line of the table lies outside the text";
+    *nout = 0;
+    return ECL_E_ARG;
+  }
+  if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
   }
   return rc;

@@ -720,6 +720,24 @@ static void mul_flush(run_t *run, int g, u64 (*ks)[4], u32 n) {
   free(buf);
   report_progress(&run->rep, n);
 }
+/* -raw: lines [at, at + n) of a chunk, hashed on the device; a hit's private key is that line's SHA-256, recomputed here */
+static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, const u64 *lines, u32 n) {
+  if (!n) return;
+  u32 cap = n * 2 + 16, cnt = 0;
+  ecl_found *buf = malloc(sizeof(ecl_found) * cap);
+  int rc = ecl_hip_mul_batch_raw(run->dev[g], text, (u32)text_len, lines, n, buf, cap, &cnt);
+  if (rc != ECL_OK) die_ecl(run, g, rc, "mul_batch_raw");
+  for (u32 i = 0; i < cnt; ++i) {
+    if (!filter_confirms(&run->flt, buf[i].h160)) continue;
+    const u64 ln = lines[buf[i].key_offset];
+    u32 st[8];
+    sha256_stream(st, text + (u32)ln, (size_t)(ln >> 32));
+    sc pk = {{(u64)st[6] << 32 | st[7], (u64)st[4] << 32 | st[5], (u64)st[2] << 32 | st[3], (u64)st[0] << 32 | st[1]}};
+    report_hit(&run->rep, buf[i].compressed, buf[i].h160, &pk);
+  }
+  free(buf);
+  report_progress(&run->rep, n);
+}
 /* cmd_mul (main.c:542-576): stdin lines -> scalars (hex, or SHA-256 of the text with -raw) -> device batches.
    The reference parses in its worker threads (main.c:503-527) and is bound by that; here the curve work is on the
    GPUs, so the text side is a three-stage pipeline that keeps every stage busy:
@@ -757,29 +775,23 @@ __attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out
 }
 static bool have_ssse3;
 #endif
-static sc line_to_scalar(const run_t *run, const char *p, size_t len) {
+/* fe_modn_from_hex (lib/ecc.c:81-95,262-265): right to left, characters that are not hex digits skipped, 64 digits at most */
+static sc line_to_scalar(const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
-  if (!run->opt.raw) { /* fe_modn_from_hex: right to left, non-hex skipped, 64 digits at most */
 #if defined(__x86_64__)
-    if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
-        hex16_ssse3(p + 48, &k.w[0]))
-      return sc_reduce(k);
-    k = (sc){{0, 0, 0, 0}};
-#endif
-    int cnt = 0;
-    for (size_t i = len; i-- > 0 && cnt < 64;) {
-      int v = HEXVAL[(u8)p[i]];
-      if (v < 0) continue;
-      k.w[cnt >> 4] |= (u64)v << ((cnt & 15) * 4);
-      cnt++;
-    }
+  if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
+      hex16_ssse3(p + 48, &k.w[0]))
     return sc_reduce(k);
+  k = (sc){{0, 0, 0, 0}};
+#endif
+  int cnt = 0;
+  for (size_t i = len; i-- > 0 && cnt < 64;) {
+    int v = HEXVAL[(u8)p[i]];
+    if (v < 0) continue;
+    k.w[cnt >> 4] |= (u64)v << ((cnt & 15) * 4);
+    cnt++;
   }
-  u32 st[8];
-  sha256_stream(st, (const u8 *)p, len);
-  k.w[0] = (u64)st[6] << 32 | st[7], k.w[1] = (u64)st[4] << 32 | st[5];
-  k.w[2] = (u64)st[2] << 32 | st[3], k.w[3] = (u64)st[0] << 32 | st[1];
-  return k;
+  return sc_reduce(k);
 }
 typedef struct {
   const run_t *run;
@@ -798,7 +810,7 @@ static void *parse_worker(void *arg) {
     if (len && s->buf[at + len - 1] == '\r') len--;
     if (len) {
       if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 32);
-      sc k = line_to_scalar(s->run, s->buf + at, len);
+      sc k = line_to_scalar(s->buf + at, len);
       memcpy(s->tmp[n++], k.w, 32);
     }
     at = stop + 1;
@@ -830,6 +842,37 @@ static void *parse_fixed_worker(void *arg) {
   }
   s->ok = true;
 #endif
+  return NULL;
+}
+
+/* -raw: nothing is parsed on the host - a slice's bytes go into the chunk's page-locked text buffer as they are, and its
+   non-empty lines are listed (offset | length << 32, '\r' before the newline dropped); the GPU computes the SHA-256s */
+typedef struct {
+  const char *buf; u8 *text_dst;
+  size_t beg, end;
+  u64 *tmp; size_t tmp_cap, count;
+  u64 *dst;
+} raw_slice;
+static void *raw_scan_worker(void *arg) {
+  raw_slice *s = arg;
+  memcpy(s->text_dst + s->beg, s->buf + s->beg, s->end - s->beg);
+  size_t n = 0, at = s->beg;
+  while (at < s->end) {
+    const char *nl = memchr(s->buf + at, '\n', s->end - at);
+    size_t stop = nl ? (size_t)(nl - s->buf) : s->end, len = stop - at;
+    if (len && s->buf[at + len - 1] == '\r') len--;
+    if (len) {
+      if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 8);
+      s->tmp[n++] = (u64)at | (u64)len << 32;
+    }
+    at = stop + 1;
+  }
+  s->count = n;
+  return NULL;
+}
+static void *raw_pack_worker(void *arg) {
+  raw_slice *s = arg;
+  memcpy(s->dst, s->tmp, s->count * 8);
   return NULL;
 }
 
@@ -923,7 +966,7 @@ static void *copy_worker(void *arg) {
 
 /* text chunks: reader thread -> parser */
 #define MUL_TEXT_CHUNK ((size_t)64 << 20) /* hex lines and -bin: ~1 M / 2 M scalars per chunk */
-#define MUL_RAW_CHUNK ((size_t)16 << 20)  /* -raw: pass phrases are a quarter as long as hex keys - about as many scalars per chunk */
+#define MUL_RAW_CHUNK ((size_t)32 << 20)  /* -raw: pass phrases are a quarter as long as hex keys - ~2 M lines per chunk */
 #define MUL_TEXT_RING 3
 typedef struct { char *buf, *own; size_t len; } text_chunk; /* buf = own (a ring buffer) or a slice of the mapped input */
 typedef struct {
@@ -1004,7 +1047,11 @@ static void *mul_reader(void *arg) {
 }
 /* parsed arrays: parser -> device threads */
 #define MUL_MAX_ARRAYS (MAX_GPUS + 2)
-typedef struct { u64 (*ks)[4]; size_t cap, n; bool pinned; } scalar_array;
+typedef struct {
+  u64 (*ks)[4]; size_t cap, n; bool pinned; /* scalars (hex lines, -bin); n = entries of this chunk in either form */
+  /* -raw: the chunk's text and its line table (offset | length << 32) instead - the GPU hashes (ecl_hip_mul_batch_raw) */
+  u8 *text; size_t text_cap, text_len; u64 *lines; size_t lines_cap; bool raw_pinned;
+} scalar_array;
 /* scalar arrays live in page-locked memory so that the GPUs read them by DMA (no staging copy in ecl_hip_mul_batch) */
 static void ks_free(const run_t *run, u64 (*ks)[4], bool pinned) {
   (void)run;
@@ -1020,6 +1067,24 @@ static void ks_grow(const run_t *run, scalar_array *ar, size_t n) {
   if (!ar->ks) ar->ks = malloc(cap * 32);
   ar->cap = cap;
 }
+static void raw_grow(const run_t *run, scalar_array *ar, size_t text_bytes, size_t nlines) {
+  if (text_bytes > ar->text_cap) {
+    if (ar->text) { if (ar->raw_pinned) ecl_hip_free_host(ar->text); else free(ar->text); }
+    ar->text_cap = text_bytes + text_bytes / 8 + 4096;
+    ar->text = run->parse_only ? NULL : ecl_hip_alloc_host(ar->text_cap);
+    ar->raw_pinned = ar->text != NULL;
+    if (!ar->text) ar->text = malloc(ar->text_cap);
+  }
+  if (nlines > ar->lines_cap) {
+    if (ar->lines) { if (ar->raw_pinned) ecl_hip_free_host(ar->lines); else free(ar->lines); }
+    ar->lines_cap = nlines + nlines / 8 + 1024;
+    ar->lines = ar->raw_pinned ? ecl_hip_alloc_host(ar->lines_cap * 8) : NULL;
+    if (!ar->lines) { /* text pageable (parse_only) or the allocation failed: both pageable */
+      if (ar->raw_pinned) { u8 *t = malloc(ar->text_cap); ecl_hip_free_host(ar->text); ar->text = t, ar->raw_pinned = false; }
+      ar->lines = malloc(ar->lines_cap * 8);
+    }
+  }
+}
 /* The arrays of a run are allocated while the devices come up (bring_up starts mul_prealloc beside the device threads):
    page-locking costs 0.3 ms per MB - 45 ms for the four 33 MB arrays of a one-GPU text run, 90 ms with -bin - which the
    first chunks otherwise wait for one after the other. */
@@ -1029,9 +1094,12 @@ typedef struct { const run_t *run; int narr; } mul_prealloc_arg;
 static void *mul_prealloc(void *arg) {
   const mul_prealloc_arg *a = arg;
   const size_t per = a->run->bin ? MUL_TEXT_CHUNK / 32 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
+  const bool raw = a->run->opt.raw && !a->run->bin;
   for (int i = 0; i < a->narr && i < MUL_MAX_ARRAYS; ++i) {
-    scalar_array ar = {NULL, 0, 0, false};
-    ks_grow(a->run, &ar, per);
+    scalar_array ar;
+    memset(&ar, 0, sizeof ar);
+    if (raw) raw_grow(a->run, &ar, MUL_RAW_CHUNK, MUL_RAW_CHUNK / 12);
+    else ks_grow(a->run, &ar, per);
     mul_ready_arrays[i] = ar, mul_ready_count = i + 1;
   }
   return NULL;
@@ -1062,10 +1130,20 @@ static void *mul_device_worker(void *arg) {
     if (q->run->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
       static int quiet = -1; /* ECLOOP_HIP_PARSE_QUIET=1: the front end alone, nothing printed (timing) */
       if (quiet < 0) { const char *e = getenv("ECLOOP_HIP_PARSE_QUIET"); quiet = e && e[0] == '1'; }
-      for (size_t k = 0; k < ar->n && !quiet; ++k)
-        printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)ar->ks[k][3], (unsigned long long)ar->ks[k][2],
-               (unsigned long long)ar->ks[k][1], (unsigned long long)ar->ks[k][0]);
-    } else
+      const bool raw = q->run->opt.raw && !q->run->bin;
+      for (size_t k = 0; k < ar->n && !quiet; ++k) {
+        if (raw) { /* what the device computes from the line table: the line's SHA-256 */
+          u32 st[8];
+          sha256_stream(st, ar->text + (u32)ar->lines[k], (size_t)(ar->lines[k] >> 32));
+          printf("%08x%08x%08x%08x%08x%08x%08x%08x\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+        } else
+          printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)ar->ks[k][3], (unsigned long long)ar->ks[k][2],
+                 (unsigned long long)ar->ks[k][1], (unsigned long long)ar->ks[k][0]);
+      }
+    } else if (q->run->opt.raw && !q->run->bin)
+      for (size_t at = 0; at < ar->n; at += STEP)
+        mul_flush_raw(q->run, a->g, ar->text, ar->text_len, ar->lines + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
+    else
       for (size_t at = 0; at < ar->n; at += STEP) mul_flush(q->run, a->g, ar->ks + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
     pthread_mutex_lock(&q->mu);
     q->idle[q->nidle++] = i;
@@ -1100,8 +1178,8 @@ static void cmd_mul(run_t *run) {
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   /* pool size: the main thread and the reader keep a core each (the pool's workers spin).  Hex lines and -bin are bound by
      getting the input's pages mapped and read, which stops scaling at 16 threads on the 2 x 64-core box (text 2^27 lines:
-     16 threads 636, 32 threads 378, 64 threads 275 M lines/s); -raw is SHA-256 work and takes 32 (174 / 256 / 161) */
-  const int pool_cap = run->opt.raw && !run->bin ? 32 : 16;
+     16 threads 636, 32 threads 378, 64 threads 275 M lines/s); with -raw the GPU hashes, the host only lists the lines */
+  const int pool_cap = 16;
   int P = (int)(ncpu < 3 ? 1 : ncpu > pool_cap + 2 ? pool_cap : ncpu - 2);
   { const char *e = getenv("ECLOOP_HIP_PARSE_THREADS"); /* experiments */
     if (e && atoi(e) >= 1 && atoi(e) <= MUL_POOL_MAX) P = atoi(e); }
@@ -1122,6 +1200,8 @@ static void cmd_mul(run_t *run) {
   for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
   parse_slice sl[MUL_POOL_MAX];
   memset(sl, 0, sizeof sl);
+  static raw_slice rs[MUL_POOL_MAX];
+  memset(rs, 0, sizeof rs);
   pool_t pool;
   pool_init(&pool, P);
   u64 t_text = 0, t_array = 0, t_parse = 0, t_grow = 0, t_pack = 0, nchunks = 0, nfixed = 0, t_mark; /* us per stage (ECLOOP_HIP_STATS) */
@@ -1151,6 +1231,29 @@ static void cmd_mul(run_t *run) {
         ct[nc] = (copy_task){ar->ks + at, c->buf + at * 32, (ar->n - at < per ? ar->n - at : per) * 32};
       pool_run(&pool, copy_worker, ct, sizeof ct[0], nc);
       t_parse += us_now() - t_mark;
+    } else if (run->opt.raw) { /* text and line table for the GPU */
+      raw_grow(run, ar, c->len, 0);
+      t_grow += us_now() - t_mark, t_mark = us_now();
+      int ns = 0;
+      size_t at = 0, end = c->len;
+      for (int i = 0; i < P && at < end; ++i) {
+        size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
+        if (stop <= at) stop = at + 1;
+        while (stop < end && c->buf[stop - 1] != '\n') stop++;
+        rs[ns].buf = c->buf, rs[ns].text_dst = ar->text, rs[ns].beg = at, rs[ns].end = stop;
+        at = stop, ns++;
+      }
+      pool_run(&pool, raw_scan_worker, rs, sizeof rs[0], ns);
+      t_parse += us_now() - t_mark, t_mark = us_now();
+      size_t total = 0;
+      for (int i = 0; i < ns; ++i) total += rs[i].count;
+      raw_grow(run, ar, c->len, total);
+      t_grow += us_now() - t_mark, t_mark = us_now();
+      ar->n = total, ar->text_len = c->len;
+      size_t off = 0;
+      for (int i = 0; i < ns; ++i) rs[i].dst = ar->lines + off, off += rs[i].count;
+      pool_run(&pool, raw_pack_worker, rs, sizeof rs[0], ns);
+      t_pack += us_now() - t_mark;
     } else if (parse_fixed_chunk(run, &pool, P, c, ar, &t_grow, &t_parse, &t_mark)) {
       nfixed++; /* every line was 64 hex digits + newline: parsed in place */
     } else {
@@ -1192,8 +1295,12 @@ static void cmd_mul(run_t *run) {
   pthread_join(reader, NULL);
   for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
-  for (int i = 0; i < sq.narr; ++i) ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
-  for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp);
+  for (int i = 0; i < sq.narr; ++i) {
+    ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
+    if (sq.arr[i].raw_pinned) ecl_hip_free_host(sq.arr[i].text), ecl_hip_free_host(sq.arr[i].lines);
+    else free(sq.arr[i].text), free(sq.arr[i].lines);
+  }
+  for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp), free(rs[i].tmp);
   if (!run->parse_only) report_close(&run->rep);
   if (getenv("ECLOOP_HIP_STATS")) /* where the front end's wall time went (the main thread drives one chunk at a time) */
     fprintf(stderr, "mul front end: %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, waiting for a free array (devices behind) %.1f, "
@@ -1557,7 +1664,7 @@ static void *bringup_thread(void *arg) {
   b->t[3] = us_now();
   if (rc == ECL_OK && b->reserve_keys) rc = ecl_hip_reserve(*h, b->reserve_keys, 4096);
   if (rc == ECL_OK && run->cmd == CMD_MUL && !run->parse_only) { /* window table, staging and record buffer of a usual batch (mul_flush's sizes) */
-    const u32 n = (u32)(run->bin ? MUL_TEXT_CHUNK / 32 : MUL_TEXT_CHUNK / MUL_RECORD + 1024);
+    const u32 n = (u32)(run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024);
     rc = ecl_hip_reserve_mul(*h, n, n * 2 + 16);
   }
   b->t[4] = us_now();

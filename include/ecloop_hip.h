@@ -127,6 +127,15 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
    and freed with the last of them.  Results do not depend on the width. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
+/* `mul -raw` (main.c:505-527: the scalar of a line is the SHA-256 of its bytes, read as a big-endian number): the same as
+   ecl_hip_mul_batch with the hashing done on the device.  `text` holds the lines' bytes (anywhere, in any order, newline
+   bytes or not), lines[i] = offset of line i in `text` (low 32 bits) | its length in bytes (high 32 bits); n <= 2^22 lines
+   and text_bytes < 2^32 - 16 per call, every line inside the text (ECL_E_ARG otherwise).  key_offset of a hit = line
+   index; the caller re-derives that line's private key (one SHA-256) for the found record.  Page-locked `text` / `lines`
+   arrays are read by DMA directly. */
+int ecl_hip_mul_batch_raw(ecl_hip *h, const uint8_t *text, uint32_t text_bytes, const uint64_t *lines, uint32_t n, ecl_found *out,
+                          uint32_t cap, uint32_t *nout);
+
 /* Optional: set up now what a later ecl_hip_mul_batch of up to n scalars with record capacity `cap` needs (the window
    table of the width in force, device staging, record buffer), so that the first batch does not pay for it - the
    counterpart of ecl_hip_reserve for `mul`; the reference builds its table at the start of cmd_mul (main.c:543). */

@@ -445,3 +445,38 @@ def test_pinning_small_and_large_scalar_arrays():
         assert d.lib.ecl_hip_unpin_host(big.ctypes.data) == 0  # not pinned any more: a no-op, not an error
     finally:
         d.close()
+
+
+def test_mul_batch_raw_hashes_lines_on_the_device():
+    """`mul -raw` (main.c:505-527): the scalar of a line is its SHA-256.  ecl_hip_mul_batch_raw hashes on the device: lines
+    of every length around the padding boundaries (0, 1, 55, 56, 63, 64, 119, 120, ... several blocks), at every byte
+    alignment, must give the hits that ecl_hip_mul_batch gives for hashlib's digests; a line table that points outside the
+    text is refused."""
+    import ctypes as C
+    import hashlib
+    import random
+    from ecloop_amd import Device, capi
+    r = random.Random(3)
+    lens = list(range(0, 200)) + [r.randrange(0, 40) for _ in range(30000)] + [255, 256, 257, 1000, 1024, 4000]
+    lines = [bytes(r.getrandbits(8) for _ in range(n)) for n in lens]
+    want_k = [int.from_bytes(hashlib.sha256(l).digest(), "big") for l in lines]
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        got, n1 = d.mul_batch_raw(lines, cap=2 * len(lines))
+        ref, n2 = d.mul_batch(want_k, cap=2 * len(lines))
+        assert n1 == n2 == 2 * len(lines)
+        key = lambda a: sorted(zip(a["key_offset"].tolist(), a["compressed"].tolist(), map(tuple, a["h160"].tolist())))
+        assert key(got) == key(ref)
+        # the empty string and "abc": public known answers through the oracle
+        g, _ = d.mul_batch_raw([b"", b"abc"], cap=8)
+        for rec in g:
+            k = int.from_bytes(hashlib.sha256([b"", b"abc"][int(rec["key_offset"])]).digest(), "big") % orc.N
+            assert list(rec["h160"]) == orc.hash160(*orc.point_of(k), bool(rec["compressed"]))
+        text = np.frombuffer(b"0123456789", dtype=np.uint8)
+        table = np.array([0 | (4 << 32), 8 | (3 << 32)], dtype=np.uint64)  # the second line ends one byte after the text
+        out = np.zeros(8, dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        assert d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, 10, table.ctypes.data, 2, out.ctypes.data, 8, C.byref(cnt)) == -1  # ECL_E_ARG
+    finally:
+        d.close()
