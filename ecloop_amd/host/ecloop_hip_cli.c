@@ -1636,6 +1636,81 @@ static int run_bench(const opts_t *o) {
   return 0;
 }
 
+/* `bench-gtable` (lib/bench.c:114-141: table build time, multiplications per second and memory for window widths 8..22):
+   the same sweep over the device's window tables - here the width is a run-time property (ecl_hip_set_mul_window), so one
+   process measures them all; same line format, "gen" = first batch minus a later one (table build + check), 2^22 scalars. */
+static int run_bench_gtable(void) {
+  if (ecl_hip_device_count() <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
+  const u32 n = 1u << 22;
+  u64 (*ks)[4] = ecl_hip_alloc_host((size_t)n * 32);
+  if (!ks) { fprintf(stderr, "[!] bench-gtable: no page-locked memory\n"); return 1; }
+  u64 x = 42;
+  for (u32 i = 0; i < n; ++i)
+    for (int j = 0; j < 4; ++j) x ^= x << 13, x ^= x >> 7, x ^= x << 17, ks[i][j] = x;
+  u64 zeros[64] = {0};
+  ecl_found hit[16];
+  for (u32 w = 8; w <= 24; w += 2) {
+    ecl_hip *d = NULL;
+    u32 cnt = 0;
+    int rc = ecl_hip_open(&d, 0, ECL_ADDR33, 0);
+    if (rc == ECL_OK) rc = ecl_hip_set_bloom(d, zeros, 64);
+    if (rc == ECL_OK) rc = ecl_hip_set_mul_window(d, w);
+    const u64 t0 = us_now();
+    if (rc == ECL_OK) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt);
+    const u64 t1 = us_now();
+    const int reps = 8;
+    for (int r = 0; r < reps && rc == ECL_OK; ++r) rc = ecl_hip_mul_batch(d, ks, n, hit, 16, &cnt);
+    const u64 t2 = us_now();
+    if (rc != ECL_OK) { fprintf(stderr, "[!] bench-gtable w=%u: %s (%s)\n", w, ecl_hip_strerror(rc), d ? ecl_hip_last_error(d) : ""); return 1; }
+    const double mult = (double)(t2 - t1) / 1e6, one = mult / reps, gent = (double)(t1 - t0) / 1e6 - one;
+    const u32 nwin = (256 + w - 1) / w;
+    const double slots = (double)(nwin - 1) * (double)((1u << w) - 1) + (double)((1u << (256 - w * (nwin - 1))) - 1);
+    printf("w=%02u: %.1fK it/s | gen: %5.2fs | mul: %5.2fs | mem: %8.1fMB\n", w, (double)n * reps / mult / 1000, gent > 0 ? gent : 0, mult,
+           slots * 64 / 1024 / 1024);
+    fflush(stdout);
+    ecl_hip_close(d);
+  }
+  ecl_hip_free_host(ks);
+  return 0;
+}
+/* `mult-verify` (lib/bench.c:143-166: ec_gtable_mul against ec_jacobi_mulrdc for the scalars 2 .. 16001, silent when they
+   agree): both window-table paths of the device - ecl_hip_verify (the 14-bit table of the walk) and ecl_hip_mul_batch (its
+   own table; every hash160 comes back through an all-ones filter) - against the double-and-add kernel. */
+static int run_mult_verify(void) {
+  if (ecl_hip_device_count() <= 0) { fprintf(stderr, "no MI355X GPU visible (the search path has no CPU fallback)\n"); return 1; }
+  enum { N = 16000 };
+  static u64 ks[N][4], px[N][4], py[N][4];
+  static u32 want33[N][5], want65[N][5], got33[N][5], got65[N][5];
+  static u8 ok[N], okv[N];
+  static ecl_found hit[2 * N];
+  for (int i = 0; i < N; ++i) ks[i][0] = (u64)i + 2, ks[i][1] = ks[i][2] = ks[i][3] = 0;
+  u64 ones[64];
+  memset(ones, 0xff, sizeof ones);
+  ecl_hip *d = NULL;
+  u32 cnt = 0;
+  int rc = ecl_hip_open(&d, 0, ECL_ADDR33 | ECL_ADDR65, 0);
+  if (rc == ECL_OK) rc = ecl_hip_set_bloom(d, ones, 64);
+  if (rc == ECL_OK) rc = ecl_hip_diag_mulg(d, ks, px, py, ok, N);
+  if (rc == ECL_OK) rc = ecl_hip_diag_hash160(d, px, py, want33, want65, N);
+  if (rc == ECL_OK) rc = ecl_hip_verify(d, ks, N, got33, got65, okv);
+  if (rc == ECL_OK) rc = ecl_hip_mul_batch(d, ks, N, hit, 2 * N, &cnt);
+  if (rc != ECL_OK) { fprintf(stderr, "[!] mult-verify: %s (%s)\n", ecl_hip_strerror(rc), d ? ecl_hip_last_error(d) : ""); return 1; }
+  int bad = -1;
+  for (int i = 0; i < N && bad < 0; ++i)
+    if (!ok[i] || !okv[i] || memcmp(got33[i], want33[i], 20) || memcmp(got65[i], want65[i], 20)) bad = i;
+  if (bad < 0 && cnt != 2 * N) bad = 0;
+  for (u32 i = 0; i < cnt && bad < 0; ++i) {
+    const u64 k = hit[i].key_offset;
+    if (k >= N || memcmp(hit[i].h160, hit[i].compressed ? want33[k] : want65[k], 20)) bad = (int)k;
+  }
+  ecl_hip_close(d);
+  if (bad >= 0) {
+    printf("invalid on %d\n", bad);
+    return 1;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------- device bring-up */
 /* Device contexts of a run: context g works on GPU (g mod shown) mod real, where `shown` is the -t count clamped to
    the visible GPUs and `real` the GPUs that exist.  `mul` opens TWO contexts per GPU - a batch is one synchronous
@@ -1727,6 +1802,8 @@ int main(int argc, const char **argv) {
   if (!strcmp(verb, "blf-gen")) return cmd_blf_gen(o, argv[0]), 0;
   if (!strcmp(verb, "blf-check")) return cmd_blf_check(o, argc, argv), 0;
   if (!strcmp(verb, "bench")) return run_bench(o);
+  if (!strcmp(verb, "bench-gtable")) return run_bench_gtable();
+  if (!strcmp(verb, "mult-verify")) return run_mult_verify();
   if (!strcmp(verb, "parse")) { /* hidden: `mul`'s text front end alone (no GPU), for the parser tests */
     run.cmd = CMD_MUL, run.parse_only = true, run.ngpus = 1, run.bin = o->bin;
     report_init(&run.rep, NULL, true);

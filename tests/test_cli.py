@@ -123,6 +123,22 @@ def test_sparse_bloom_two_jobs(cli, tmp_path):
 
 
 @pytest.mark.gpu
+def test_mult_verify_and_bench_gtable_commands(cli):
+    """the reference's `mult-verify` (lib/bench.c:143-166: silent, exit 0 when the window-table products equal the
+    double-and-add ones for 2 .. 16001) and `bench-gtable` (lib/bench.c:114-141: one line per window width, same format)"""
+    pr = subprocess.run([cli, "mult-verify"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode == 0 and pr.stdout == b"", pr.stdout + pr.stderr
+    pr = subprocess.run([cli, "bench-gtable"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    rows = pr.stdout.decode().splitlines()
+    assert pr.returncode == 0 and len(rows) == 9, pr.stdout + pr.stderr
+    for w, row in zip(range(8, 26, 2), rows):
+        m = re.fullmatch(r"w=(\d\d): ([\d.]+)K it/s \| gen: +([\d.]+)s \| mul: +([\d.]+)s \| mem: +([\d.]+)MB", row)
+        assert m and int(m.group(1)) == w and float(m.group(2)) > 1000, row
+    # w = 14: 18 rows of 16383 points + the 4-bit last window's 15 (the reference allocates 19 full rows: 19.0 MB)
+    assert abs(float(re.search(r"mem: +([\d.]+)MB", rows[3]).group(1)) - 18.0) < 0.1
+
+
+@pytest.mark.gpu
 def test_mul_flows(cli, tmp_path):
     lines, status, _ = run(cli, ["mul", "-f", os.path.join(GOLD, "btc-bw-hash"), "-a", "cu"], stdin_path=os.path.join(GOLD, "btc-bw-priv"),
                            out=str(tmp_path / "m.txt"))
