@@ -1312,9 +1312,16 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum over 19 x 14 bits is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  const u32 chunk = h->kbuf_cap;
+  // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel: 2^20 scalars, 2^21 for calls of
+  // 2^25 and more, and the first piece a quarter of the others - nothing overlaps its copy.  Measured, M scalars/s by call
+  // size 2^22 / 2^24 / 2^26 (profiles/r03_mul_pieces.txt): 22-bit table, pieces of 2^20: 848 / 970 / 994, 2^21: 803 / 947 /
+  // 1034, 2^22 (one piece per call up to 2^22: 2.6 ms of copy and then the kernel): 622 / 894 / 1006; 18-bit table:
+  // 768 / 850 / 870, 729 / 869 / 908, 565 / 813 / 896.  Fewer than 2^17 threads per kernel cost more than they save
+  // (pieces of 2^19 with 8 scalars per thread: 735 / 776 / 782 on 18 bits).
+  u32 chunk = h->kbuf_cap;
+  const u32 piece = n >= (1u << 25) ? 1u << 21 : 1u << 20;
+  if (piece < chunk) chunk = piece;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  // the first chunk of a long call is a quarter of the others: nothing overlaps its copy, the kernel starts 2 ms earlier
   for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c) {
     const u32 b = c & 1, lim = c == 0 && n > chunk ? chunk / 4 : chunk;
     m = n - at < lim ? n - at : lim;
