@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
 ]
 
 _lib = None
@@ -69,6 +69,7 @@ def load():
     lib.ecl_hip_unpin_host.argtypes = [C.c_void_p]
     lib.ecl_hip_set_mul_window.argtypes = [P, C.c_uint32]
     lib.ecl_hip_reserve_mul.argtypes = [P, C.c_uint32, C.c_uint32]
+    lib.ecl_hip_sort_list.argtypes = [P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ecl_hip_mul_batch_raw.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_mul_window.argtypes = [P, C.POINTER(C.c_uint32)]
     lib.ecl_hip_verify.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -203,6 +204,13 @@ class Device:
     def set_mul_window(self, bits):
         """window width of this context's `mul` table (8..24; 0 = automatic: 18, then 22 after 2^29 scalars)"""
         self._chk(self.lib.ecl_hip_set_mul_window(self.h, bits))
+
+    def sort_list(self, h160):
+        """(n, 5) uint32 hash160 words -> the sorted (compare_160 order), duplicate-free entries"""
+        a = np.ascontiguousarray(h160, dtype=np.uint32).copy()
+        kept = C.c_uint64()
+        self._chk(self.lib.ecl_hip_sort_list(self.h, a.ctypes.data, len(a), C.byref(kept)))
+        return a[: kept.value]
 
     def reserve_mul(self, n, cap=4096):
         self._chk(self.lib.ecl_hip_reserve_mul(self.h, n, cap))

@@ -150,6 +150,32 @@ static u64 us_now(void) {
 }
 static void erase_status_line(void) { fputs("\033[2K\r", stderr); }
 
+/* hex digits: table for the general readers, 16 characters at a time where SSSE3 is there */
+static signed char HEXVAL[256];
+static void hexval_init(void) {
+  memset(HEXVAL, -1, sizeof HEXVAL);
+  for (int c = '0'; c <= '9'; ++c) HEXVAL[c] = (signed char)(c - '0');
+  for (int c = 'a'; c <= 'f'; ++c) HEXVAL[c] = (signed char)(c - 'a' + 10), HEXVAL[c - 32] = (signed char)(c - 'a' + 10);
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* 16 hex characters (most significant first) -> one little-endian u64; false if any character is not a hex digit */
+__attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out) {
+  const __m128i c = _mm_loadu_si128((const __m128i *)p);
+  const __m128i lower = _mm_or_si128(c, _mm_set1_epi8(0x20));
+  const __m128i isdig = _mm_and_si128(_mm_cmpgt_epi8(c, _mm_set1_epi8('0' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('9' + 1), c));
+  const __m128i isalp = _mm_and_si128(_mm_cmpgt_epi8(lower, _mm_set1_epi8('a' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('f' + 1), lower));
+  if (_mm_movemask_epi8(_mm_or_si128(isdig, isalp)) != 0xFFFF) return false;
+  const __m128i nib = _mm_add_epi8(_mm_and_si128(c, _mm_set1_epi8(0x0F)), _mm_and_si128(isalp, _mm_set1_epi8(9)));
+  const __m128i pair = _mm_maddubs_epi16(nib, _mm_set1_epi16(0x0110)); /* first digit * 16 + second digit */
+  const __m128i bytes = _mm_packus_epi16(pair, pair);                   /* 8 bytes, most significant first */
+  const __m128i rev = _mm_shuffle_epi8(bytes, _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7));
+  *out = (u64)_mm_cvtsi128_si64(rev);
+  return true;
+}
+#endif
+static bool have_ssse3; /* set once in main */
+
 /* ------------------------------------------------------------------------------------------- command line */
 /* Every option of every command, parsed in ONE pass over argv into this struct: a flag that takes a value consumes the
    next argument, anything else is left alone (`blf-check` reads hashes from the bare words).  Spelling and meaning of
@@ -245,10 +271,20 @@ static int order160(const void *a, const void *b) { /* compare_160, addr.c:18-26
 }
 /* 40 hex digits -> 5 words; false if any character is not a hex digit */
 static bool hash160_from_hex(const char *s, u32 h[5]) {
+#if defined(__x86_64__)
+  if (have_ssse3) { /* 16 + 16 characters, then the last 8 padded with zeros on the left */
+    u64 a, b, c;
+    char tail[16] = {'0', '0', '0', '0', '0', '0', '0', '0'};
+    memcpy(tail + 8, s + 32, 8);
+    if (!hex16_ssse3(s, &a) || !hex16_ssse3(s + 16, &b) || !hex16_ssse3(tail, &c)) return false;
+    h[0] = (u32)(a >> 32), h[1] = (u32)a, h[2] = (u32)(b >> 32), h[3] = (u32)b, h[4] = (u32)c;
+    return true;
+  }
+#endif
   for (int w = 0; w < 5; ++w) {
     u32 v = 0;
     for (int d = 0; d < 8; ++d) {
-      int c = (unsigned char)s[w * 8 + d], x = c >= '0' && c <= '9' ? c - '0' : (c | 32) >= 'a' && (c | 32) <= 'f' ? (c | 32) - 'a' + 10 : -1;
+      int x = HEXVAL[(u8)s[w * 8 + d]];
       if (x < 0) return false;
       v = v << 4 | (u32)x;
     }
@@ -259,18 +295,15 @@ static bool hash160_from_hex(const char *s, u32 h[5]) {
 /* Entries of a hash list, as the reference's reader sees them (main.c:96-110: fgets into a 41-byte buffer consumes a line
    in pieces of 40 characters, and every FULL piece is an entry).  Stated on the file image: cut at '\n', walk each line
    in steps of 40, keep the pieces that are 40 clean hex digits (the reference parses garbage out of the others - one
-   phantom entry for the comment line of data/btc-bw-hash; dropped here).  out == NULL: count only. */
+   phantom entry for the comment line of data/btc-bw-hash; dropped here).  `out` has room for len / 40 + 1
+   entries (no piece is shorter than 40 characters). */
 static size_t hashlist_entries(const char *text, size_t len, u32 *out) {
   size_t n = 0;
   for (size_t at = 0; at < len;) {
     const char *nl = memchr(text + at, '\n', len - at);
     size_t eol = nl ? (size_t)(nl - text) : len;
-    for (size_t p = at; p + 40 <= eol; p += 40) {
-      u32 h[5];
-      if (!hash160_from_hex(text + p, h)) continue;
-      if (out) memcpy(out + n * 5, h, 20);
-      n++;
-    }
+    for (size_t p = at; p + 40 <= eol; p += 40)
+      if (hash160_from_hex(text + p, out + n * 5)) n++;
     at = eol + 1;
   }
   return n;
@@ -297,14 +330,38 @@ static void filter_open(filter_t *f, const char *path) {
     if (why) { fprintf(stderr, "%s\n", why); exit(1); }
     return;
   }
+  const bool stats = getenv("ECLOOP_HIP_STATS") != NULL;
+  u64 t0 = us_now();
   size_t len;
   char *text = slurp(in, &len);
   fclose(in);
-  size_t n = hashlist_entries(text, len, NULL);
+  u64 t1 = us_now();
+  u32 *hs = malloc((len / 40 + 1) * 20);
+  size_t n = hashlist_entries(text, len, hs);
   if (!n) { fprintf(stderr, "no hashes in filter file\n"); exit(1); }
-  u32 *hs = malloc(n * 20);
-  hashlist_entries(text, len, hs);
   free(text);
+  hs = realloc(hs, n * 20);
+  u64 t2 = us_now();
+  if (stats) fprintf(stderr, "list: %zu entries; read %.1f ms, parse %.1f ms\n", n, (t1 - t0) / 1e3, (t2 - t1) / 1e3);
+  /* long lists are sorted, made unique and turned into filter bits on GPU 0 (10^7 entries: 13 s here, qsort + 2 * 10^8
+     scattered bit sets); short ones, or no GPU (the hidden CPU-only commands), on the host */
+  if (n >= (1u << 16) && n < (1ull << 31) && !getenv("ECLOOP_HIP_LIST_ON_HOST") && ecl_hip_device_count() > 0) {
+    ecl_hip *d = NULL;
+    u64 kept = 0;
+    int rc = ecl_hip_open(&d, 0, ECL_ADDR33, 0);
+    if (rc == ECL_OK) rc = ecl_hip_sort_list(d, (uint32_t(*)[5])hs, n, &kept);
+    if (rc == ECL_OK) {
+      f->list = hs, f->nlist = kept;
+      f->nwords = 2 * kept, f->words = calloc(f->nwords, 8);
+      rc = ecl_hip_set_bloom(d, f->words, f->nwords);
+    }
+    if (rc == ECL_OK) rc = ecl_hip_bloom_insert(d, (const uint32_t(*)[5])hs, kept);
+    if (rc == ECL_OK) rc = ecl_hip_get_bloom(d, f->words, f->nwords);
+    if (rc != ECL_OK) { fprintf(stderr, "[!] preparing the hash list on the GPU failed: %s (%s)\n", ecl_hip_strerror(rc), d ? ecl_hip_last_error(d) : ""); exit(1); }
+    ecl_hip_close(d);
+    if (stats) fprintf(stderr, "list: sorted, %zu unique, filter bits set on GPU 0 in %.1f ms (context included)\n", (size_t)kept, (us_now() - t2) / 1e3);
+    return;
+  }
   qsort(hs, n, 20, order160);
   size_t kept = 1;
   for (size_t i = 1; i < n; ++i)
@@ -312,6 +369,7 @@ static void filter_open(filter_t *f, const char *path) {
   f->list = hs, f->nlist = kept;
   f->nwords = 2 * kept, f->words = calloc(f->nwords, 8);
   for (size_t i = 0; i < kept; ++i) bloom_set(f, hs + i * 5);
+  if (stats) fprintf(stderr, "list: sorted, %zu unique, filter bits set on the host in %.1f ms\n", kept, (us_now() - t2) / 1e3);
 }
 /* second stage of ctx_check_hash (main.c:212-216): the device reports bloom hits, the list decides */
 static bool filter_confirms(const filter_t *f, const u32 h[5]) {
@@ -751,30 +809,6 @@ static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, co
    feeders that can produce more than text parsing can take.
    Difference kept small on purpose: a line longer than 1024 characters is one line here (the reference's fgets
    splits it, main.c:552). */
-static signed char HEXVAL[256];
-static void hexval_init(void) {
-  memset(HEXVAL, -1, sizeof HEXVAL);
-  for (int c = '0'; c <= '9'; ++c) HEXVAL[c] = (signed char)(c - '0');
-  for (int c = 'a'; c <= 'f'; ++c) HEXVAL[c] = (signed char)(c - 'a' + 10), HEXVAL[c - 32] = (signed char)(c - 'a' + 10);
-}
-#if defined(__x86_64__)
-#include <immintrin.h>
-/* 16 hex characters (most significant first) -> one little-endian u64; false if any character is not a hex digit */
-__attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out) {
-  const __m128i c = _mm_loadu_si128((const __m128i *)p);
-  const __m128i lower = _mm_or_si128(c, _mm_set1_epi8(0x20));
-  const __m128i isdig = _mm_and_si128(_mm_cmpgt_epi8(c, _mm_set1_epi8('0' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('9' + 1), c));
-  const __m128i isalp = _mm_and_si128(_mm_cmpgt_epi8(lower, _mm_set1_epi8('a' - 1)), _mm_cmpgt_epi8(_mm_set1_epi8('f' + 1), lower));
-  if (_mm_movemask_epi8(_mm_or_si128(isdig, isalp)) != 0xFFFF) return false;
-  const __m128i nib = _mm_add_epi8(_mm_and_si128(c, _mm_set1_epi8(0x0F)), _mm_and_si128(isalp, _mm_set1_epi8(9)));
-  const __m128i pair = _mm_maddubs_epi16(nib, _mm_set1_epi16(0x0110)); /* first digit * 16 + second digit */
-  const __m128i bytes = _mm_packus_epi16(pair, pair);                   /* 8 bytes, most significant first */
-  const __m128i rev = _mm_shuffle_epi8(bytes, _mm_set_epi8(-1, -1, -1, -1, -1, -1, -1, -1, 0, 1, 2, 3, 4, 5, 6, 7));
-  *out = (u64)_mm_cvtsi128_si64(rev);
-  return true;
-}
-static bool have_ssse3;
-#endif
 /* fe_modn_from_hex (lib/ecc.c:81-95,262-265): right to left, characters that are not hex digits skipped, 64 digits at most */
 static sc line_to_scalar(const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
@@ -1170,10 +1204,6 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
 }
 static void cmd_mul(run_t *run) {
   report_restart_clock(&run->rep);
-  hexval_init();
-#if defined(__x86_64__)
-  have_ssse3 = __builtin_cpu_supports("ssse3");
-#endif
   have_sha_ni = cpu_has_sha();
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   /* pool size: the main thread and the reader keep a core each (the pool's workers spin).  Hex lines and -bin are bound by
@@ -1794,6 +1824,10 @@ static void print_scalar_row(const char *name, const sc *v) {
 }
 int main(int argc, const char **argv) {
   setlocale(LC_NUMERIC, "");
+  hexval_init();
+#if defined(__x86_64__)
+  have_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
   static run_t run;
   opts_t *o = &run.opt;
   opts_parse(o, argc, argv);

@@ -96,6 +96,12 @@ int ecl_hip_get_bloom(ecl_hip *h, uint64_t *bits, uint64_t nwords);
    and colliding hashes (the bits are those of ecl_hip_bloom_insert). */
 int ecl_hip_bloom_insert_count(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n, uint64_t *added);
 
+/* load_filter's list preparation (main.c:96-131: qsort by compare_160, duplicates stay; here they are dropped) on the device:
+   sorts the n entries of h160 in place into compare_160 order (addr.c:18-26: word by word), removes duplicates, *kept =
+   entries left at the front of the array.  n < 2^31.  10^7 entries: 13 s of qsort + bit setting on the host, well under a
+   second here (the bits: ecl_hip_set_bloom of a zero filter + ecl_hip_bloom_insert + ecl_hip_get_bloom). */
+int ecl_hip_sort_list(ecl_hip *h, uint32_t (*h160)[5], uint64_t n, uint64_t *kept);
+
 /* Optional exact confirm on the device: the second half of ctx_check_hash (main.c:212-216).  h160 = the n sorted,
    unique list entries (ctx->to_find_hashes, order of compare_160, addr.c:18-26).  With a list resident, add_range /
    mul_batch report a hash only if it passed the bloom probe AND is in the list (a small kernel after the search

@@ -123,6 +123,25 @@ def test_sparse_bloom_two_jobs(cli, tmp_path):
 
 
 @pytest.mark.gpu
+def test_long_hash_list_prepared_on_the_device(cli, tmp_path):
+    """a list of >= 2^16 entries is sorted, made unique and turned into filter bits on the GPU (ecl_hip_sort_list); the run
+    must find what the host-prepared list finds (ECLOOP_HIP_LIST_ON_HOST=1), duplicates and all"""
+    import random
+    import orc
+    r = random.Random(16)
+    want = [orc.hash160(*orc.point_of(k), True) for k in (0x8123, 0x9abc, 0xfff0)]
+    entries = ["%040x" % r.getrandbits(160) for _ in range(70000)] + ["".join("%08x" % w for w in h) for h in want]
+    entries += entries[:500]  # duplicates
+    r.shuffle(entries)
+    lst = tmp_path / "big.txt"
+    lst.write_text("\n".join(entries) + "\n")
+    a, sa, _ = run(cli, ["add", "-f", str(lst), "-r", "8000:ffff"], out=str(tmp_path / "a.txt"))
+    b, sb, _ = run(cli, ["add", "-f", str(lst), "-r", "8000:ffff"], out=str(tmp_path / "b.txt"), env=dict(os.environ, ECLOOP_HIP_LIST_ON_HOST="1"))
+    assert sorted(a) == sorted(b) and len(a) == 3 and counts(sa) == counts(sb)
+    assert sorted(l.split("\t")[2][-4:] for l in a) == ["8123", "9abc", "fff0"]
+
+
+@pytest.mark.gpu
 def test_mult_verify_and_bench_gtable_commands(cli):
     """the reference's `mult-verify` (lib/bench.c:143-166: silent, exit 0 when the window-table products equal the
     double-and-add ones for 2 .. 16001) and `bench-gtable` (lib/bench.c:114-141: one line per window width, same format)"""

@@ -480,3 +480,42 @@ def test_mul_batch_raw_hashes_lines_on_the_device():
         assert d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, 10, table.ctypes.data, 2, out.ctypes.data, 8, C.byref(cnt)) == -1  # ECL_E_ARG
     finally:
         d.close()
+
+
+def test_sort_list_on_the_device_equals_qsort_by_compare_160():
+    """ecl_hip_sort_list: load_filter's qsort by compare_160 (main.c:112, addr.c:18-26: word by word, unsigned) + duplicate
+    removal, on the device; entries that differ only in the last / only in the first word, runs of duplicates, and the
+    filter bits of the result equal to the host's blf_add loop"""
+    from ecloop_amd import Device
+    rng = np.random.default_rng(160)
+    n = 300_000
+    a = rng.integers(0, 1 << 32, (n, 5), dtype=np.uint64).astype(np.uint32)
+    a[1000:2000] = a[0:1000]                    # duplicates far apart
+    a[5000:5100] = a[5000]                      # a run of one value
+    a[6000:7000, :4] = a[6000, :4]              # equal but for the last word
+    a[8000:9000, 1:] = a[8000, 1:]              # equal but for the first word
+    a[9000] = 0
+    a[9001] = 0xFFFFFFFF
+    d = Device(0)
+    try:
+        got = d.sort_list(a)
+        order = np.lexsort(tuple(a[:, k] for k in (4, 3, 2, 1, 0)))
+        s = a[order]
+        keep = np.ones(n, dtype=bool)
+        keep[1:] = (s[1:] != s[:-1]).any(axis=1)
+        want = s[keep]
+        assert got.shape == want.shape and np.array_equal(got, want)
+        d.set_list(got)  # the ABI's own check of "sorted and unique" accepts it
+        words = np.zeros(2 * len(got), dtype=np.uint64)
+        d.set_bloom(words)
+        d.bloom_insert(got)
+        bits = d.get_bloom(len(words))
+        flt = orc.OrcFilter(hashes=got)  # the oracle's load_filter: 2 words per entry, blf_add of every entry
+        assert flt.f.size == len(words) and np.array_equal(np.ctypeslib.as_array(flt.f.bits, shape=(flt.f.size,)), bits)
+    finally:
+        d.close()
+    d = Device(0)
+    try:
+        assert len(d.sort_list(a[:1])) == 1 and len(d.sort_list(np.repeat(a[:1], 1000, axis=0))) == 1
+    finally:
+        d.close()
