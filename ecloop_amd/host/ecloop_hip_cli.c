@@ -1429,12 +1429,31 @@ static void cmd_rnd(run_t *run) {
 /* ------------------------------------------------------------------------------------------- blf-gen / blf-check */
 /* hash160 lines of a text stream, a batch at a time (lines are read the way filter_open reads a list: 40-character
    pieces, clean hex only) */
-typedef struct { FILE *in; char carry[41]; } hash_lines_t;
-static size_t hash_lines_next(hash_lines_t *s, u32 (*out)[5], size_t want) {
-  size_t n = 0;
-  while (n < want && fgets(s->carry, sizeof s->carry, s->in))
-    if (strlen(s->carry) == 40 && hash160_from_hex(s->carry, out[n])) n++;
-  return n;
+/* hash lines of blf-gen / blf-check on stdin, a block at a time.  The reference reads with fgets into a 41-byte buffer
+   (utils.c:451-466): a line is consumed in pieces of 40 characters and every full piece of 40 hex digits is an entry -
+   hashlist_entries() on the block, which is cut at its last newline (the rest is carried into the next block). */
+#define HASH_BLOCK ((size_t)64 << 20)
+#define HASH_BLOCK_ENTRIES (HASH_BLOCK / 40 + 1)
+typedef struct { FILE *in; char *buf; size_t have; bool eof; } hash_lines_t;
+static size_t hash_lines_next(hash_lines_t *s, u32 (*out)[5]) { /* out: room for HASH_BLOCK_ENTRIES; 0 = end of input */
+  if (!s->buf) s->buf = malloc(HASH_BLOCK);
+  for (;;) {
+    if (!s->eof) {
+      size_t got = fread(s->buf + s->have, 1, HASH_BLOCK - s->have, s->in);
+      s->have += got;
+      if (s->have < HASH_BLOCK) s->eof = true;
+    }
+    if (!s->have) return 0;
+    size_t end = s->have;
+    if (!s->eof) {
+      while (end > 0 && s->buf[end - 1] != '\n') end--;
+      if (end == 0) end = s->have / 40 * 40; /* one line longer than the block: whole pieces now, the rest stays */
+    }
+    const size_t n = hashlist_entries(s->buf, end, (u32 *)out);
+    memmove(s->buf, s->buf + end, s->have - end);
+    s->have -= end;
+    if (n || (s->eof && !s->have)) return n;
+  }
 }
 /* blf-gen -n <count> -o <file> < hashes (utils.c:409-475): a filter sized for n entries at a false-positive rate of 1e-9,
    created or - if the file exists with that size - updated; prints how many of the hashes were new.  Filters for 2^16
@@ -1465,7 +1484,7 @@ static void cmd_blf_gen(const opts_t *o, const char *prog) {
   }
   printf("bloom filter params: n = %'llu | p = 1:%'llu | m = %'llu (%'.1f MB)\n", (unsigned long long)n, (unsigned long long)one_in,
          (unsigned long long)m_bits, (double)m_bits / 8 / 1024 / 1024);
-  hash_lines_t lines = {stdin, ""};
+  hash_lines_t lines = {stdin, NULL, 0, false};
   u64 fresh = 0;
   ecl_hip *dev = NULL;
   if (n >= (1u << 16) && !o->host_only && ecl_hip_device_count() > 0) {
@@ -1474,9 +1493,8 @@ static void cmd_blf_gen(const opts_t *o, const char *prog) {
     if (rc != ECL_OK) { fprintf(stderr, "[!] GPU set-up failed: %s (%s)\n", ecl_hip_strerror(rc), dev ? ecl_hip_last_error(dev) : ""); exit(1); }
     printf("inserting on GPU 0\n");
   }
-  const size_t batch = dev ? (size_t)1 << 22 : 4096;
-  u32 (*hs)[5] = malloc(batch * 20);
-  for (size_t got; (got = hash_lines_next(&lines, hs, batch)) > 0;) {
+  u32 (*hs)[5] = malloc(HASH_BLOCK_ENTRIES * 20);
+  for (size_t got; (got = hash_lines_next(&lines, hs)) > 0;) {
     if (dev) {
       u64 added = 0;
       int rc = ecl_hip_bloom_insert_count(dev, (const uint32_t(*)[5])hs, got, &added);
