@@ -78,7 +78,7 @@ done
 : > "$O/pmc_mul.txt"
 for set in "SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "VALUBusy"; do
   ECL_HIP_SKIP_SELFTEST=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmcm" -o p -- python "$R/bench.py" --cmd mul --steps 1 --warmup 1 > "$O/pmcm.log" 2>&1
-  echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 2 x 2^24 scalars, -a cu)" >> "$O/pmc_mul.txt"
+  echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 3 x 2^24 scalars, -a cu, 22-bit window table)" >> "$O/pmc_mul.txt"
   summ "$O/pmcm" k_mul_check >> "$O/pmc_mul.txt"
   rm -rf "$O/pmcm"
 done
@@ -93,8 +93,8 @@ for line in open(sys.argv[1]):
     if line.startswith("# --pmc"): passes += 1
     if f and f[0] == "PMC": pmc[f[2]] = (float(f[3]), int(f[4]))
     if f and f[0] == "TRACE": ns.append(int(f[2]))
-scalars = 2 * (1 << 24)  # warm-up + one step
-out = {"tag": sys.argv[2], "kernel": "k_mul_check<addr33,addr65>", "workload": "bench.py --cmd mul: 2^24 scalars per step, -a cu, R = 16 scalars per thread, window table W = 22 (12 additions per scalar)",
+scalars = 3 * (1 << 24)  # the call that builds the table + warm-up + one step
+out = {"tag": sys.argv[2], "kernel": "k_mul_check<addr33,addr65>", "workload": "bench.py --cmd mul: 2^24 scalars per step, -a cu, pieces of 2^20 scalars, 8 per thread, window table W = 22 (12 additions per scalar)",
        "pmc": {k: v[0] for k, v in pmc.items()}, "dispatches": {k: v[1] for k, v in pmc.items()}, "derived": {}}
 if "SQ_INSTS_VALU" in pmc:
     out["derived"]["valu_lane_ops_per_scalar"] = pmc["SQ_INSTS_VALU"][0] * 64 / scalars
