@@ -169,22 +169,53 @@ __host__ __device__ inline wtab wtab_make(const u32* p, u32 W) {
   return t;
 }
 __host__ __device__ inline size_t wtab_slots(const wtab& t) { return (size_t)(t.nwin - 1u) * t.per + t.top_per; }
+#ifndef ECL_WTAB_PREFETCH
+#define ECL_WTAB_PREFETCH 1  /* 0: load a window's point when it is added (A/B) */
+#endif
+__device__ __forceinline__ u32 wtab_digit(const u32 kk[9], const wtab& t, u32 w) {
+  const u32 bit = w * t.W, word = bit >> 5, sh = bit & 31;
+  u32 lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
+    if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+  }
+  return (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // kk[8] = 0: the last window is as narrow as it is
+}
+// The point of window w + 1 is requested before the addition of window w's (64 bytes, 16 registers held across one
+// mixed addition): the gathers come from HBM / Infinity Cache and the kernel runs at two waves per SIMD, too few to hide them.
+// Measured on 2^24-scalar calls, 22-bit table, four processes each: 995-1001 M scalars/s with, 980-985 without.
 __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
   jac acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#if ECL_WTAB_PREFETCH
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  u32 dnext = wtab_digit(kk, t, 0);
+  if (dnext) {
+    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
 #pragma unroll 1
   for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 bit = w * t.W, word = bit >> 5, sh = bit & 31;
-    u32 lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
-      if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+    const u32 digit = dnext;
+    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    if (dnext) {
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
-    const u32 digit = (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // kk[8] = 0: the last window is as narrow as it is
+    if (!digit) continue;
+    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    acc = jac_madd(acc, fe_from_words(xw), fe_from_words(yw));
+  }
+#else
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = wtab_digit(kk, t, w);
     if (!digit) continue;
     const u32* e = t.p + ((size_t)w * t.per + digit - 1) * 16;
     acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
   }
+#endif
   return acc;
 }
 // rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
