@@ -807,8 +807,8 @@ static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, co
                      main.c:556-571)
    `-bin` (not in the reference): stdin carries the scalars themselves, 32 bytes each (4 little-endian u64 = `fe`), for
    feeders that can produce more than text parsing can take.
-   Difference kept small on purpose: a line longer than 1024 characters is one line here (the reference's fgets
-   splits it, main.c:552). */
+   A line longer than 1024 characters is read in pieces of 1024, each an entry of its own, as the reference's
+   fgets(line, 1025) does (main.c:548-552). */
 /* fe_modn_from_hex (lib/ecc.c:81-95,262-265): right to left, characters that are not hex digits skipped, 64 digits at most */
 static sc line_to_scalar(const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
@@ -827,6 +827,7 @@ static sc line_to_scalar(const char *p, size_t len) {
   }
   return sc_reduce(k);
 }
+#define MUL_LINE_MAX 1024u /* main.c:18,548: MAX_LINE_SIZE - 1 characters per fgets */
 typedef struct {
   const run_t *run;
   const char *buf;
@@ -840,11 +841,13 @@ static void *parse_worker(void *arg) {
   size_t n = 0, at = s->beg;
   while (at < s->end) {
     const char *nl = memchr(s->buf + at, '\n', s->end - at);
-    size_t stop = nl ? (size_t)(nl - s->buf) : s->end, len = stop - at;
-    if (len && s->buf[at + len - 1] == '\r') len--;
-    if (len) {
+    const size_t stop = nl ? (size_t)(nl - s->buf) : s->end;
+    for (size_t q = at; q < stop; q += MUL_LINE_MAX) { /* the reference's fgets(line, 1025): a longer line is read in pieces */
+      size_t len = stop - q < MUL_LINE_MAX ? stop - q : MUL_LINE_MAX;
+      if (s->buf[q + len - 1] == '\r') len--;
+      if (!len) continue;
       if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 32);
-      sc k = line_to_scalar(s->buf + at, len);
+      sc k = line_to_scalar(s->buf + q, len);
       memcpy(s->tmp[n++], k.w, 32);
     }
     at = stop + 1;
@@ -893,11 +896,13 @@ static void *raw_scan_worker(void *arg) {
   size_t n = 0, at = s->beg;
   while (at < s->end) {
     const char *nl = memchr(s->buf + at, '\n', s->end - at);
-    size_t stop = nl ? (size_t)(nl - s->buf) : s->end, len = stop - at;
-    if (len && s->buf[at + len - 1] == '\r') len--;
-    if (len) {
+    const size_t stop = nl ? (size_t)(nl - s->buf) : s->end;
+    for (size_t q = at; q < stop; q += MUL_LINE_MAX) { /* pieces of 1024 characters, as the reference's fgets reads them */
+      size_t len = stop - q < MUL_LINE_MAX ? stop - q : MUL_LINE_MAX;
+      if (s->buf[q + len - 1] == '\r') len--;
+      if (!len) continue;
       if (n >= s->tmp_cap) s->tmp_cap = s->tmp_cap ? s->tmp_cap * 2 : 1 << 16, s->tmp = realloc(s->tmp, s->tmp_cap * 8);
-      s->tmp[n++] = (u64)at | (u64)len << 32;
+      s->tmp[n++] = (u64)q | (u64)len << 32;
     }
     at = stop + 1;
   }

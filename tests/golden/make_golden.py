@@ -131,7 +131,31 @@ def rnd_cases(g, tmp):
     print(f"rnd_windows_d128_21: {len(wins)} complete windows, found {[w['found'] for w in wins]}")
 
 
+def long_line_cases(g, tmp):
+    """cmd_mul's reader: fgets(line, 1025) (main.c:18,548-552) hands a line longer than 1024 characters over in pieces.
+    The input is a committed data file (tests/golden/mul_long_lines.txt); the reference's found lines through the all-ones
+    filter, -raw and hex, are the fixture."""
+    import random
+    ones = os.path.join(tmp, "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    r = random.Random(1024)
+    hx = lambda n: "".join(r.choice("0123456789abcdef") for _ in range(n))
+    lines = [hx(64), hx(2500), hx(1024), hx(1025), hx(1023) + "\r" + "ab", "x" * 3000, "abc", "z" * 2047 + "\r", "%064x" % 5]
+    path = os.path.join(HERE, "mul_long_lines.txt")
+    open(path, "w", newline="").write("\n".join(lines) + "\n")
+    for name, extra in (("mul_long_lines_raw", ["-raw"]), ("mul_long_lines_hex", [])):
+        found, status = run_ref(["mul", "-f", ones, "-t", "1"] + extra, open(path, "rb"))
+        g["cases"][name] = {"args": ["mul", "-f", "<all-ones .blf>", "-t", "1"] + extra, "stdin": "tests/golden/mul_long_lines.txt",
+                            "count": len(found), "lines": found, "status": status_counts(status)}
+        print(f"{name}: {len(found)} lines, status {status_counts(status)}")
+
+
 def main():
+    if "--only-long-lines" in sys.argv:
+        g = json.load(open(os.path.join(HERE, "golden.json")))
+        long_line_cases(g, tempfile.mkdtemp())
+        json.dump(g, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+        return
     if "--only-rnd" in sys.argv:  # add / refresh the rnd cases without touching the other fixtures
         g = json.load(open(os.path.join(HERE, "golden.json")))
         rnd_cases(g, tempfile.mkdtemp())
@@ -209,6 +233,7 @@ def main():
     g["cases"]["blf_gen_puzzles_32768"] = {"bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest(),
                                            "header_hex": raw[:16].hex(), "size_words": struct.unpack("<Q", raw[8:16])[0]}
     rnd_cases(g, tmp)
+    long_line_cases(g, tmp)
     # inputs owned by the reference's data/ directory: stored as data fixtures for the GPU box
     for name in ("btc-puzzles-hash", "btc-bw-hash", "btc-bw-priv"):
         dst = os.path.join(HERE, name)

@@ -429,6 +429,49 @@ def test_mul_parser_fixed_record_path_and_its_fallback(cli):
     assert _parse(cli, crlf) == want[:1000]
 
 
+def test_mul_lines_longer_than_1024_characters_are_read_in_pieces(cli):
+    """cmd_mul reads with fgets(line, 1025) (main.c:18,548-552): a longer line arrives in pieces of 1024 characters, each an
+    entry of its own (a '\\r' at the end of a piece is dropped, empty pieces are skipped) - hex and -raw"""
+    import random
+    import orc
+    r = random.Random(1024)
+    def pieces(line):
+        out = []
+        for q in range(0, len(line), 1024):
+            p = line[q:q + 1024]
+            if p.endswith("\r"):
+                p = p[:-1]
+            if p:
+                out.append(p)
+        return out
+    hexl = ["%064x" % r.getrandbits(256), "".join(r.choice("0123456789abcdef") for _ in range(2500)),
+            "".join(r.choice("0123456789abcdef") for _ in range(1024)), "".join(r.choice("0123456789abcdef") for _ in range(1025)),
+            "".join(r.choice("0123456789abcdef") for _ in range(1023)) + "\r" + "ab", "%064x" % 5]
+    want = ["%064x" % orc.sn_from_hex(p) for l in hexl for p in pieces(l)]
+    assert _parse(cli, ("\n".join(hexl) + "\n").encode()) == want
+    rawl = ["x" * 3000, "abc", "y" * 1024, "z" * 2047 + "\r"]
+    want = [hashlib.sha256(p.encode()).hexdigest() for l in rawl for p in pieces(l)]
+    assert _parse(cli, ("\n".join(rawl) + "\n").encode(), "-raw") == want
+
+
+def test_mul_long_lines_against_the_references_reader(cli):
+    """the same, pinned to the reference: its found lines (all-ones filter) for tests/golden/mul_long_lines.txt, hex and -raw,
+    carry the private key of every piece it read; the front end must produce exactly those scalars"""
+    data = open(os.path.join(GOLD, "mul_long_lines.txt"), "rb").read()
+    for name, flag in (("mul_long_lines_hex", ()), ("mul_long_lines_raw", ("-raw",))):
+        want = sorted(l.split("\t")[2] for l in G[name]["lines"])
+        assert sorted(_parse(cli, data, *flag)) == want and len(want) == 16
+
+
+@pytest.mark.gpu
+def test_mul_long_lines_found_lines_equal_the_references(cli, tmp_path):
+    ones = str(tmp_path / "ones.blf")
+    write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
+    for name, flag in (("mul_long_lines_hex", []), ("mul_long_lines_raw", ["-raw"])):
+        lines, status, _ = run(cli, ["mul", "-f", ones] + flag, stdin_path=os.path.join(GOLD, "mul_long_lines.txt"), out=str(tmp_path / (name + ".txt")))
+        assert lines == sorted(G[name]["lines"]) and list(counts(status)) == G[name]["status"]
+
+
 def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
     """-raw = SHA-256 of the line (main.c:505-527) for lengths around the padding boundaries; -bin passes 32-byte
     little-endian scalars through; an input of several 64 MB chunks keeps every line, in order"""
