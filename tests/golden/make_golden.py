@@ -140,12 +140,13 @@ def long_line_cases(g, tmp):
     write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
     r = random.Random(1024)
     hx = lambda n: "".join(r.choice("0123456789abcdef") for _ in range(n))
-    lines = [hx(64), hx(2500), hx(1024), hx(1025), hx(1023) + "\r" + "ab", "x" * 3000, "abc", "z" * 2047 + "\r", "%064x" % 5]
-    path = os.path.join(HERE, "mul_long_lines.txt")
-    open(path, "w", newline="").write("\n".join(lines) + "\n")
-    for name, extra in (("mul_long_lines_raw", ["-raw"]), ("mul_long_lines_hex", [])):
+    hexl = [hx(64), hx(2500), hx(1024), hx(1025), hx(1023) + "\r" + "ab", "abc", "%064x" % 5]
+    rawl = hexl + ["x" * 3000, "z" * 2047 + "\r"]  # (as hex these would be the scalar 0, which ruins the reference's whole batch)
+    for name, extra, lines in (("mul_long_lines_raw", ["-raw"], rawl), ("mul_long_lines_hex", [], hexl)):
+        path = os.path.join(HERE, name + ".txt")
+        open(path, "w", newline="").write("\n".join(lines) + "\n")
         found, status = run_ref(["mul", "-f", ones, "-t", "1"] + extra, open(path, "rb"))
-        g["cases"][name] = {"args": ["mul", "-f", "<all-ones .blf>", "-t", "1"] + extra, "stdin": "tests/golden/mul_long_lines.txt",
+        g["cases"][name] = {"args": ["mul", "-f", "<all-ones .blf>", "-t", "1"] + extra, "stdin": "tests/golden/" + name + ".txt",
                             "count": len(found), "lines": found, "status": status_counts(status)}
         print(f"{name}: {len(found)} lines, status {status_counts(status)}")
 

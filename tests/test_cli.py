@@ -455,12 +455,12 @@ def test_mul_lines_longer_than_1024_characters_are_read_in_pieces(cli):
 
 
 def test_mul_long_lines_against_the_references_reader(cli):
-    """the same, pinned to the reference: its found lines (all-ones filter) for tests/golden/mul_long_lines.txt, hex and -raw,
+    """the same, pinned to the reference: its found lines (all-ones filter) for tests/golden/mul_long_lines_{hex,raw}.txt
     carry the private key of every piece it read; the front end must produce exactly those scalars"""
-    data = open(os.path.join(GOLD, "mul_long_lines.txt"), "rb").read()
     for name, flag in (("mul_long_lines_hex", ()), ("mul_long_lines_raw", ("-raw",))):
+        data = open(os.path.join(GOLD, name + ".txt"), "rb").read()
         want = sorted(l.split("\t")[2] for l in G[name]["lines"])
-        assert sorted(_parse(cli, data, *flag)) == want and len(want) == 16
+        assert sorted(_parse(cli, data, *flag)) == want and len(want) == G[name]["count"] >= 11
 
 
 @pytest.mark.gpu
@@ -468,7 +468,7 @@ def test_mul_long_lines_found_lines_equal_the_references(cli, tmp_path):
     ones = str(tmp_path / "ones.blf")
     write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
     for name, flag in (("mul_long_lines_hex", []), ("mul_long_lines_raw", ["-raw"])):
-        lines, status, _ = run(cli, ["mul", "-f", ones] + flag, stdin_path=os.path.join(GOLD, "mul_long_lines.txt"), out=str(tmp_path / (name + ".txt")))
+        lines, status, _ = run(cli, ["mul", "-f", ones] + flag, stdin_path=os.path.join(GOLD, name + ".txt"), out=str(tmp_path / (name + ".txt")))
         assert lines == sorted(G[name]["lines"]) and list(counts(status)) == G[name]["status"]
 
 
