@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Differential fuzz of the `mul` path on the GPU box: random batch sizes (1 .. 2^22+, so that 1, 2, 4, 8 and 16 scalars
 per thread and several staged chunks all occur), random 256-bit scalars with zeros / n / small values mixed in,
-address selections, filters of several sizes and densities, pageable and page-locked scalar arrays.  Every hit set of
-ecl_hip_mul_batch (window table + ONE inversion per thread) must equal the one derived independently: double-and-add
-kernel -> hash kernel -> the oracle's blf_has on the host.
+address selections, filters of several sizes and densities, pageable and page-locked scalar arrays, the window width of the
+table fixed at random (8 .. 24 bits) or automatic; every third trial feeds text lines to ecl_hip_mul_batch_raw (`mul -raw`:
+SHA-256 of the line on the device; lengths 0 .. 300, any alignment) with hashlib's digests as the scalars of the yardstick.
+Every hit set of ecl_hip_mul_batch / _raw (window table + ONE inversion per thread) must equal the one derived independently:
+double-and-add kernel -> hash kernel -> the oracle's blf_has on the host.
 usage: python tools/fuzz_mul_gpu.py [seconds=120] [seed=1]      -> gpurun_out/fuzz_mul.txt"""
 import ctypes as C
 import os
@@ -44,17 +46,35 @@ def main():
         if mode == "ones" and n > (1 << 20):
             words = synth_bloom_words(nw, 7, "a|b")  # keep the record count of the big batches moderate
         pinned = rnd.random() < 0.5
+        window = rnd.choice([0, 0, rnd.randrange(8, 25)])
+        raw = trials % 3 == 2
+        if raw:  # the scalars ARE the SHA-256 digests of random lines
+            import hashlib
+            n = min(n, 1 << 18)
+            lens = rng.integers(0, rnd.choice([20, 70, 300]), n)
+            blob = rng.integers(0, 256, int(lens.sum()) + 8, dtype=np.uint8).tobytes()
+            starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64)
+            table = starts | (lens.astype(np.uint64) << np.uint64(32))
+            K = np.zeros((n, 4), dtype=np.uint64)
+            for i in range(n):
+                v = int.from_bytes(hashlib.sha256(blob[int(starts[i]): int(starts[i]) + int(lens[i])]).digest(), "big")
+                K[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+            text = np.frombuffer(blob, dtype=np.uint8)
         if os.environ.get("FUZZ_VERBOSE"):
-            print("trial", trials, dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned), flush=True)
+            print("trial", trials, dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, window=window, raw=raw), flush=True)
         d = Device(0, a33=a33, a65=a65)
         try:
             d.set_bloom(words)
+            d.set_mul_window(window)
             if pinned:
                 assert d.lib.ecl_hip_pin_host(K.ctypes.data, K.nbytes) == 0
             cap = 2 * n + 16
             out = np.zeros(cap, dtype=capi.FOUND_DTYPE)
             cnt = C.c_uint32()
-            rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
+            if raw:
+                rc = d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, int(lens.sum()), table.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
+            else:
+                rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
             if pinned:
                 d.lib.ecl_hip_unpin_host(K.ctypes.data)
             assert rc == 0, rc
@@ -77,7 +97,7 @@ def main():
                 want.add((int(i), comp, tuple(int(v) for v in hh[i])))
         got = {(int(r["key_offset"]), int(r["compressed"]), tuple(int(v) for v in r["h160"])) for r in out[: cnt.value]}
         if got != want or cnt.value != len(want):
-            print("MISMATCH", dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, got=len(got), want=len(want), seed=seed, trial=trials))
+            print("MISMATCH", dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, window=window, raw=raw, got=len(got), want=len(want), seed=seed, trial=trials))
             sys.exit(1)
         trials, scalars, hits = trials + 1, scalars + n, hits + len(want)
     line = "# tools/fuzz_mul_gpu.py %s %d: %d trials, %d scalars, %d compared hits, ALL EQUAL to the double-and-add path + oracle blf_has" % (
