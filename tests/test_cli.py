@@ -562,6 +562,32 @@ def test_mul_fans_out_over_device_threads(cli, tmp_path, mode):
     assert counts(status) == (2160, len(lines_in))
 
 
+@pytest.mark.gpu
+def test_mul_raw_fans_out_over_device_threads(cli, tmp_path):
+    """`mul -raw -t 4`: pass phrases in several 32 MB chunks, hashed on the device (ecl_hip_mul_batch_raw) by whichever of
+    the four device threads is idle; 200 target phrases, each twice and far apart, must be found exactly twice with the
+    private key SHA-256(phrase) (main.c:505-527) and nothing else; the counter equals the number of non-empty lines"""
+    import orc
+    from collections import Counter
+    targets = ["correct horse battery staple %d" % i for i in range(200)]
+    keys = [int.from_bytes(hashlib.sha256(t.encode()).digest(), "big") for t in targets]
+    hs = [orc.hash160(*orc.point_of(k % orc.N), True) for k in keys]
+    lst = tmp_path / "targets.txt"
+    lst.write_text("".join("".join("%08x" % w for w in h) + "\n" for h in hs))
+    fill = ["filler phrase %07d" % i for i in range(2_400_000)]  # 21 bytes a line: 50 MB a block
+    src = tmp_path / "phrases.txt"
+    with open(src, "w") as f:
+        for block in (fill, targets, [""], fill, targets):
+            f.write("\n".join(block) + "\n")
+    env = dict(os.environ, ECLOOP_HIP_SHARE_GPU="4")
+    lines, status, stdout = run(cli, ["mul", "-raw", "-f", str(lst), "-t", "4"], stdin_path=str(src), out=str(tmp_path / "r.txt"), env=env)
+    assert "gpus: 4 " in stdout
+    c = Counter(lines)
+    want = {"addr33\t%s\t%064x" % ("".join("%08x" % w for w in h), k) for h, k in zip(hs, keys)}
+    assert set(c) == want and set(c.values()) == {2}
+    assert counts(status) == (400, 2 * len(fill) + 2 * len(targets))
+
+
 def test_scan_plan_matches_the_oracles_job_loop(cli):
     """the hidden `plan` command prints what scan_plan() derives from -r / -d: keys hashed and status counter of
     cmd_add (main.c:405-454).  Compared with the oracle, which RUNS the reference's job loop (counter stepping by
