@@ -9,8 +9,10 @@
  *   batch_add(ctx, pk, iterations)          main.c:349    ecl_hip_add_range()
  *     + check_found_add / check_hash        main.c:278-347  (device: hash160 + bloom probe; hits returned)
  *   ctx_precompute_gpoints(ctx)             main.c:219    done inside ecl_hip_open()/first add_range
- *   ec_gtable_mul xN + ec_jacobi_grprdc
- *     + check_found_mul                     main.c:531-534  ecl_hip_mul_batch()
+ *   ec_gtable_init, ec_gtable_mul xN        ecc.c:876-929
+ *     + ec_jacobi_grprdc + check_found_mul  main.c:531-534  ecl_hip_mul_batch()  (window tables built on the device)
+ *   SHA-256 of each line under -raw         main.c:505-527  ecl_hip_mul_batch_raw()  (hashed on the device)
+ *   qsort + blf_add loop of load_filter     main.c:112-131  optional: ecl_hip_sort_list() + ecl_hip_bloom_insert()
  *   blf_has(&ctx->blf, h)                   utils.c:308   device probe of the bits given to ecl_hip_set_bloom()
  *   bsearch(to_find_hashes) in ctx_check_hash main.c:212-216  optional: ecl_hip_set_list() (else on the host, as before)
  *   ctx->check_addr33/65, use_endo, ord_offs main.c:32-34,67  flags / ord_offs of ecl_hip_open()
