@@ -91,3 +91,38 @@ def test_mul_matches_the_reference_binary(tmp_path):
     # the reference's tail batch (main.c:467) also emits stale slots beyond the last key: compare the real keys' lines
     want = [l for l in lines if int(l.split("\t")[2], 16) in {k % orc.N for k in ks}]
     assert rc == 0 and sorted(set(want)) == sorted(set(mine)) and len(set(mine)) == 2 * len(set(k % orc.N for k in ks))
+
+
+def test_host_program_blf_gen_reads_lines_like_the_reference(tmp_path):
+    """blf-gen's reader (utils.c:451-466: fgets into a 41-byte buffer) against the host program's block reader on input with
+    every well-formed oddity: long lines (several 40-character pieces), short lines, CRLF, blank lines, a comment, upper case, a
+    duplicate, no newline at the end - same .blf bytes and the same "added N new items" (host insert loop, no GPU needed)"""
+    from ecloop_amd.build import build_host_cli
+    cli = build_host_cli()
+    r = random.Random(41)
+    hx = lambda n: "".join(r.choice("0123456789abcdef") for _ in range(n))
+    lines = [hx(40) for _ in range(3000)]
+    lines[5] = hx(80)                 # two entries
+    lines[6] = hx(100)                # two entries and 20 characters that are none
+    lines[7] = hx(38)                 # none (a piece must fill the 40 characters: 39 digits + the newline would, and the
+    #                                   reference's sscanf then makes an entry of it - the malformed-input quirk class of
+    #                                   DESIGN.md section 6, not reproduced; likewise 40 characters that are not all hex digits)
+    lines[8] = hx(40).upper()
+    lines[9] = lines[10]              # duplicate
+    lines[12] = ""
+    lines[13] = hx(40) + "\r"
+    lines[14] = "# comment"
+    lines[15] = hx(41)
+    text = "\n".join(lines)           # no newline at the end
+    src = tmp_path / "hashes.txt"
+    src.write_text(text, newline="")
+    outs = []
+    for prog, extra in ((REF, []), (cli, ["-host"])):
+        out = tmp_path / (os.path.basename(prog) + ".blf")
+        pr = subprocess.run([prog, "blf-gen", "-n", "4096", "-o", str(out)] + extra, stdin=open(src, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        if pr.returncode != 0 and prog == REF:
+            pytest.skip("the reference binary does not run on this host")
+        assert pr.returncode == 0, pr.stderr
+        added = int("".join(c for c in re.search(r"added ([\d,.\s]+) new items", pr.stdout.decode()).group(1) if c.isdigit()))
+        outs.append((added, open(out, "rb").read()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], (outs[0][0], outs[1][0])
