@@ -151,7 +151,48 @@ def long_line_cases(g, tmp):
         print(f"{name}: {len(found)} lines, status {status_counts(status)}")
 
 
+def odd_list_case(g, tmp):
+    """load_filter's list reader (main.c:96-110: fgets into a 41-byte buffer, every full 40-character piece an entry) on a
+    well-formed but oddly laid out list: the hash160s of 48 keys of 0x8000..0x87ff (taken from the reference's own dump of
+    that range) one, two and three to a line, upper case, CRLF, between blank lines, short comments and short junk.  The
+    list is a committed data file; the reference's found lines for `add -r 8000:87ff` are the fixture."""
+    import random
+    d = np.load(os.path.join(HERE, "dump33_8000_87ff.npz"))
+    r = random.Random(4040)
+    pick = sorted(r.sample(range(len(d["h160"])), 48))
+    hexes = ["".join("%08x" % w for w in d["h160"][i]) for i in pick]
+    filler = lambda: "".join(r.choice("0123456789abcdef") for _ in range(40))
+    out, i = [], 0
+    while i < len(hexes):
+        kind = r.randrange(7)
+        if kind == 0:
+            out.append(hexes[i]); i += 1
+        elif kind == 1 and i + 2 <= len(hexes):
+            out.append(hexes[i] + hexes[i + 1]); i += 2
+        elif kind == 2 and i + 3 <= len(hexes):
+            out.append(hexes[i] + filler() + hexes[i + 1] + hexes[i + 2] + "abc"); i += 3      # 160 characters + a short tail
+        elif kind == 3:
+            out.append(hexes[i].upper() + "\r"); i += 1
+        elif kind == 4:
+            out += ["", "# short comment", filler()]
+        elif kind == 5:
+            out.append(hexes[i]); out.append(hexes[i]); i += 1                                  # duplicate
+        else:
+            out.append("deadbeef")                                                              # too short to be an entry
+    path = os.path.join(HERE, "odd-list.txt")
+    open(path, "w", newline="").write("\n".join(out))                                           # no newline at the end
+    found, status = run_ref(["add", "-f", path, "-r", "8000:87ff", "-t", "1"])
+    g["cases"]["odd_list_8000_87ff"] = {"args": ["add", "-f", "tests/golden/odd-list.txt", "-r", "8000:87ff", "-t", "1"], "count": len(found),
+                                        "lines": found, "status": status_counts(status)}
+    print(f"odd_list_8000_87ff: {len(found)} lines, status {status_counts(status)}")
+
+
 def main():
+    if "--only-odd-list" in sys.argv:
+        g = json.load(open(os.path.join(HERE, "golden.json")))
+        odd_list_case(g, tempfile.mkdtemp())
+        json.dump(g, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
+        return
     if "--only-long-lines" in sys.argv:
         g = json.load(open(os.path.join(HERE, "golden.json")))
         long_line_cases(g, tempfile.mkdtemp())
@@ -235,6 +276,7 @@ def main():
                                            "header_hex": raw[:16].hex(), "size_words": struct.unpack("<Q", raw[8:16])[0]}
     rnd_cases(g, tmp)
     long_line_cases(g, tmp)
+    odd_list_case(g, tmp)
     # inputs owned by the reference's data/ directory: stored as data fixtures for the GPU box
     for name in ("btc-puzzles-hash", "btc-bw-hash", "btc-bw-priv"):
         dst = os.path.join(HERE, name)

@@ -59,6 +59,23 @@ def test_blf_gen_and_check_byte_exact(cli, tmp_path):
     assert pr.stdout.decode().splitlines() == [h + " FOUND", "00" * 20 + " NOT FOUND"]
 
 
+def test_odd_list_layout_read_like_the_reference_host_side():
+    """the 48 hash160s the reference finds through tests/golden/odd-list.txt (one, two, three to a line, upper case, CRLF,
+    blank lines, short comments, no final newline: main.c:96-110) are all entries of the list the Python mirror loads"""
+    from ecloop_amd.engine import load_filter
+    flt = load_filter(os.path.join(GOLD, "odd-list.txt"))
+    have = {"".join("%08x" % int(w) for w in e) for e in flt.hashes}
+    want = {l.split("\t")[1] for l in G["odd_list_8000_87ff"]["lines"]}
+    assert len(want) == 48 and want <= have
+
+
+@pytest.mark.gpu
+def test_odd_list_layout_found_lines_equal_the_references(cli, tmp_path):
+    lines, status, _ = run(cli, ["add", "-f", os.path.join(GOLD, "odd-list.txt"), "-r", "8000:87ff", "-t", "1"], out=str(tmp_path / "o.txt"))
+    g = G["odd_list_8000_87ff"]
+    assert lines == sorted(g["lines"]) and list(counts(status)) == g["status"]
+
+
 def test_usage_and_version(cli):
     assert "ecloop-hip v" in subprocess.run([cli, "-v"], stdout=subprocess.PIPE).stdout.decode()
     assert "blf-gen" in subprocess.run([cli], stdout=subprocess.PIPE).stdout.decode()
