@@ -406,6 +406,35 @@ __global__ void k_mix_by_wave_prio(uint32_t* out, uint32_t seed) {
   if (s == 0x12345) out[0] = s;
 }
 
+// round 3: the multiplier against the other opcode classes, by wave: the waves of odd blocks run v_mad_u64_u32, the even ones
+// another stream.  If 64-bit multiply-adds and plain ALU operations went through units that overlap, the mean per
+// instruction would fall below the mean of the two streams run alone (4.6 and 4.2 / 2.4).
+#define MIX_MAD_WITH(NAME, OTHER_ASM)                                                            \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                          \
+    uint32_t r[8], a = seed ^ threadIdx.x, b = a * 7 + 1;                                       \
+    uint64_t q[8];                                                                              \
+    for (int i = 0; i < 8; ++i) r[i] = a * (i + 3), q[i] = (uint64_t)r[i] * 0x9E3779B1u;        \
+    if (blockIdx.x & 1) {                                                                       \
+      for (int it = 0; it < ITERS; ++it) {                                                      \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i)                                         \
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(a), "v"(b) : "vcc"); \
+        }                                                                                       \
+      }                                                                                         \
+    } else {                                                                                    \
+      for (int it = 0; it < ITERS; ++it) {                                                      \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) OTHER_ASM;                              \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    uint32_t s = 0; for (int i = 0; i < 8; ++i) s ^= r[i] ^ (uint32_t)q[i] ^ (uint32_t)(q[i] >> 32); \
+    if (s == 0x12345) out[0] = s;                                                               \
+  }
+MIX_MAD_WITH(k_mix_mad_alignbit, asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)))
+MIX_MAD_WITH(k_mix_mad_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(r[i]) : "v"(a)))
+MIX_MAD_WITH(k_mix_mad_add3, asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)))
+
 typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Entry { const char* name; kern_t k; double per_iter; };
 
@@ -448,6 +477,9 @@ int main(int argc, char** argv) {
       {"v_or3_b32", k_or3_b32_d, 32}, {"v_add_lshl_u32", k_add_lshl_u32_d, 32}, {"v_mad_u32_u16", k_mad_u32_u16_d, 32},
       {"v_dot4_u32_u8", k_dot4_u32_u8_d, 32},
       {"mix 16 add + 16 alignbit, in pairs", k_mix_pairs, 32}, {"mix 4 add (2 pairs) + 28 alignbit", k_mix_pair_in_14, 32},
+      // round 3: is the 64-bit multiplier a unit of its own?
+      {"half the waves mad_u64, half alignbit", k_mix_mad_alignbit, 32}, {"half the waves mad_u64, half add", k_mix_mad_add, 32},
+      {"half the waves mad_u64, half add3", k_mix_mad_add3, 32},
   };
   int waves_per_simd = argc > 1 ? atoi(argv[1]) : 8;
   int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD
