@@ -1498,7 +1498,9 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
       size_t capw = (size_t)1 << 22;  // 16 MB of text
       while (capw < text_words) capw <<= 1;
       HIPCHK(h, hipMalloc(&h->d_rawtext, capw * 4));
-      HIPCHK(h, hipMemset(h->d_rawtext, 0, capw * 4));
+      // (hipMemset is asynchronous to the host and runs on the legacy stream, which the context's non-blocking streams do not
+      // wait for: the clearing goes on the copy stream, in front of the text that is copied there next)
+      HIPCHK(h, hipMemsetAsync(h->d_rawtext, 0, capw * 4, h->copy_stream));
       h->rawtext_cap = capw;
     }
     if (n > h->rawlines_cap) {
