@@ -519,3 +519,27 @@ def test_sort_list_on_the_device_equals_qsort_by_compare_160():
         assert len(d.sort_list(a[:1])) == 1 and len(d.sort_list(np.repeat(a[:1], 1000, axis=0))) == 1
     finally:
         d.close()
+
+
+def test_mul_batch_raw_first_call_of_many_fresh_contexts():
+    """the first raw call of a context allocates and clears its text buffer; the clearing once ran on the legacy stream and
+    could land on text already copied (lines hashed wrong, now and then).  Forty fresh contexts, a text of several MB each,
+    first call compared with the scalars' own path."""
+    import hashlib
+    from ecloop_amd import Device
+    rng = np.random.default_rng(77)
+    blob = rng.integers(97, 123, 6_000_000, dtype=np.uint8).tobytes()
+    lines = [blob[i: i + 60] for i in range(0, len(blob), 60)][:100_000]
+    ks = [int.from_bytes(hashlib.sha256(l).digest(), "big") for l in lines[::997]]
+    flt = np.zeros(64, dtype=np.uint64)
+    for trial in range(40):
+        d = Device(0)
+        try:
+            d.set_bloom(ONES)
+            got, n = d.mul_batch_raw(lines, cap=len(lines))
+            ref, m = d.mul_batch(ks, cap=len(ks))
+            assert n == len(lines) and m == len(ks)
+            by_off = {int(r["key_offset"]): tuple(r["h160"]) for r in got}
+            assert [by_off[i * 997] for i in range(len(ks))] == [tuple(r["h160"]) for r in sorted(ref, key=lambda r: r["key_offset"])], trial
+        finally:
+            d.close()
