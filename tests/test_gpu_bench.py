@@ -88,3 +88,13 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--keys-log2", "24", "--no-cpu"],
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert pr.returncode != 0 and b"GPU(s) visible" in pr.stderr and not pr.stdout.strip()
+
+
+def test_bench_cmd_mul_line():
+    """`bench.py --cmd mul` (non-headline): one JSON line, the 22-bit window table in use, rates consistent"""
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cmd", "mul", "--mul-log2", "21", "--steps", "2", "--warmup", "1"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
+    r = last_json(pr.stdout)
+    assert r["unit"] == "Mscalars/s" and r["config"]["window_bits"] == 22 and r["n_gpus"] == 1
+    assert abs(r["value"] - (1 << 21) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3 and r["value"] > 100
