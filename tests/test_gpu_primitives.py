@@ -128,6 +128,24 @@ def test_c_abi_error_codes():
         assert lib.ecl_hip_add_range(h, start, 4096, None, 0, C.byref(n)) == -4 and n.value == 4096
         for rc in range(-7, 1):
             assert lib.ecl_hip_strerror(rc)
+        # round-3 entry points
+        bits = C.c_uint32(9)
+        assert lib.ecl_hip_set_mul_window(h, 7) == -1 and lib.ecl_hip_set_mul_window(h, 25) == -1 and lib.ecl_hip_set_mul_window(None, 18) == -1
+        assert lib.ecl_hip_get_mul_window(h, C.byref(bits)) == 0 and bits.value == 0 and lib.ecl_hip_get_mul_window(h, None) == -1
+        assert lib.ecl_hip_reserve_mul(h, 0, 16) == -1 and lib.ecl_hip_reserve_mul(None, 16, 16) == -1
+        text = np.frombuffer(b"abcdef", dtype=np.uint8)
+        table = np.array([0 | (6 << 32)], dtype=np.uint64)
+        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, (1 << 22) + 1, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_mul_batch_raw(h, None, 6, table.ctypes.data, 1, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, None, 1, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, 0, out.ctypes.data, 16, C.byref(n)) == 0 and n.value == 0
+        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, 1, out.ctypes.data, 16, C.byref(n)) == 0 and n.value == 1  # all-ones filter
+        kept = C.c_uint64(5)
+        hs = np.zeros((4, 5), dtype=np.uint32)
+        assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 1 << 31, C.byref(kept)) == -1 and lib.ecl_hip_sort_list(h, None, 4, C.byref(kept)) == -1
+        assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 4, None) == -1
+        assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 0, C.byref(kept)) == 0 and kept.value == 0
+        assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 4, C.byref(kept)) == 0 and kept.value == 1
     finally:
         lib.ecl_hip_close(h)
     lib.ecl_hip_close(None)  # no-op
