@@ -543,3 +543,39 @@ def test_mul_batch_raw_first_call_of_many_fresh_contexts():
             assert [by_off[i * 997] for i in range(len(ks))] == [tuple(r["h160"]) for r in sorted(ref, key=lambda r: r["key_offset"])], trial
         finally:
             d.close()
+
+
+def test_full_size_range_equals_its_parts_and_the_oracle_on_samples():
+    """size-independent properties at BASELINE.json's full size (2^32 keys, addr33): the found set of ONE 2^32-key call equals
+    the union of four 2^30-key calls and of 2^29-key calls on a second context with another walk geometry (a GPU's shard
+    on 8 GPUs); the hit count is what the filter's density predicts; every hit is confirmed by the oracle's blf_has on the
+    hash the double-and-add kernel derives for that key"""
+    from ecloop_amd import Device
+    words = synth_bloom_words(1 << 20, 99, "a")  # density 0.5: 2^32 * 2^-20 = 4096 expected hits
+    A = 0x100000000
+    d, e = Device(0), Device(0)
+    try:
+        d.set_bloom(words), e.set_bloom(words)
+        whole, n = d.add_range(A, 1 << 32, cap=1 << 14)
+        assert n == len(whole) and 3700 < n < 4500
+        key = lambda recs, base: {(base + int(r["key_offset"]), tuple(int(v) for v in r["h160"])) for r in recs}
+        want = key(whole, A)
+        parts = set()
+        for q in range(4):
+            recs, m = d.add_range(A + (q << 30), 1 << 30, cap=1 << 13)
+            parts |= key(recs, A + (q << 30))
+        assert parts == want
+        e.set_geometry(256, 1 << 19)
+        eighths = set()
+        for q in range(8):
+            recs, m = e.add_range(A + (q << 29), 1 << 29, cap=1 << 13)
+            eighths |= key(recs, A + (q << 29))
+        assert eighths == want
+        ks = sorted(k for k, _ in want)
+        xs, ys, ok = d.diag_mulg(ks)
+        h33, _ = d.diag_hash160(xs, ys)
+        assert all(ok) and {(k, tuple(int(v) for v in h)) for k, h in zip(ks, h33)} == want
+        flt = orc.OrcFilter(bloom_words=words)
+        assert all(flt.check([int(v) for v in h]) for h in h33)
+    finally:
+        d.close(), e.close()
