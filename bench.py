@@ -412,8 +412,8 @@ def bench_mul(args, sync, dev_index, emit):
             raise SystemExit("[bench] cannot pin the scalar array")
     out = np.zeros(64, dtype=np.dtype([("b", "u1", (32,))]))
     cnt = C.c_uint32()
-    # steady state of a long run: the 22-bit window table at once (left alone a context starts on 18 bits and moves to 22
-    # after 2^29 scalars - more than this bench multiplies); `--mul-window 0` measures the automatic choice instead
+    # steady state of a long run: the 22-bit window table at once (left alone a context starts on 20 bits and moves to 22
+    # after 2^30 scalars - more than this bench multiplies); `--mul-window 0` measures the automatic choice instead
     ks.dev.set_mul_window(args.mul_window)
     t_tab = time.perf_counter()
 

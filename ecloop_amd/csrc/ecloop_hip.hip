@@ -152,8 +152,8 @@ __device__ __forceinline__ jac gtable_mul(const u32 kk[9], const u32* __restrict
 // cache (lib/ecc.c:876, `bench-gtable` sweeps it); on a 288 GB part W = 22 costs 3.0 GB and turns 19 additions per
 // scalar into 12 (one per non-zero digit).  Same method, same results; measured on 2^24-scalar calls, -a cu, device
 // time: W = 14 725 M scalars/s, 16 811, 18 842, 20 878, 22 919, 24 (11.8 GB) 965 (profiles/r03_mul_w_sweep.txt).
-// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 18, 252 MB,
-// built in a few ms, and moves to W = 22 once it has seen enough scalars to pay for the 50 ms build: ecl_hip_mul_batch).
+// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 20, 872 MB,
+// and moves to W = 22 once it has seen enough scalars to pay for the 50 ms build: ecl_hip_mul_batch).
 // The rows are not built by millions of double-and-add ladders but the way the walk's lane centres are: row w is
 // P_w, 2 P_w, 3 P_w, ... with P_w = 2^(W w) G - the points C0 + g D of k_init_centres_batched with C0 = D = P_w -
 // 44 multiplications per entry, one inversion per 16 entries; the ladder points 2^j P_w of every row come from one
@@ -1216,10 +1216,10 @@ static int ensure_gtable(ecl_hip* h) {
 // are compared with the double-and-add kernel.
 #define MUL_W_MIN 8u
 #define MUL_W_MAX 24u
-#define MUL_W_START 18u               /* 14 rows x 2^18 points, 252 MB: built in a few ms */
+#define MUL_W_START 20u               /* 13 rows x 2^20 points, 872 MB: first call 48 ms against 41 ms at 14 bits and 47 at 18 */
 #define MUL_W_LONG 22u                /* 12 rows x 2^22 points, 3.0 GB: ~50 ms */
-#define MUL_LONG_AFTER (1ull << 29)   /* scalars a context has seen before it moves to MUL_W_LONG: at 842 vs 919 M scalars/s the
-                                         wider table gains 0.1 ns per scalar, so its build is paid back after 5 * 10^8 of them */
+#define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: at 955 vs 1006 M scalars/s the
+                                         wider table gains 0.05 ns per scalar, so its build is paid back after 10^9 of them */
 struct multab_t {
   u32* d = nullptr;
   int refs = 0;

@@ -355,8 +355,8 @@ def test_mul_every_window_width_against_double_and_add(W):
         d.close()
 
 
-def test_mul_moves_to_the_long_table_after_2_pow_29_scalars_with_identical_results():
-    """automatic width: 18 bits until the context has seen 2^29 scalars, 22 bits from then on (the call that crosses the
+def test_mul_moves_to_the_long_table_after_2_pow_30_scalars_with_identical_results():
+    """automatic width: 20 bits until the context has seen 2^30 scalars, 22 bits from then on (the call that crosses the
     line already runs on the long table); two contexts on the device share each table; same hits before and after"""
     import ctypes as C
     from ecloop_amd import Device, capi
@@ -371,11 +371,11 @@ def test_mul_moves_to_the_long_table_after_2_pow_29_scalars_with_identical_resul
             dev.set_bloom(flt)
         out = np.zeros(1 << 16, dtype=capi.FOUND_DTYPE)
         cnt = C.c_uint32()
-        for call in range(130):  # 130 * 2^22 > 2^29
+        for call in range(259):  # 258 * 2^22 > 2^30
             dev = d if call != 64 else d2  # the second context stays on the short table
             assert dev.lib.ecl_hip_mul_batch(dev.h, K.ctypes.data, n, out.ctypes.data, len(out), C.byref(cnt)) == 0
-            assert dev.mul_window() == (22 if dev is d and call >= 128 else 18)  # d's 128th call (call 64 went to d2) completes 2^29
-            if call in (0, 64, 126, 127, 128, 129):
+            assert dev.mul_window() == (22 if dev is d and call >= 256 else 20)  # d's 256th call (call 64 went to d2) completes 2^30
+            if call in (0, 64, 254, 255, 256, 258):
                 r = out[: cnt.value]
                 hits.append(sorted(zip(r["key_offset"].tolist(), map(tuple, r["h160"].tolist()))))
         assert len(hits[0]) > 100 and all(h == hits[0] for h in hits)
