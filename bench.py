@@ -50,6 +50,7 @@ PLANTED = 16
 PEAK_4CYCLE = 256 * 4 * 16 * 2.4e9 / 1e12
 PEAK_2CYCLE = 2 * PEAK_4CYCLE
 HBM_PEAK_GBS = 8000.0
+DATA = "synthetic"  # what the line's `data` field says
 ALGO_BYTES_PER_KEY = 18 + 18 + 1.59 * 8  # chain element (36 B) written + read per two keys; 1.59 probes x 8 B
 
 
@@ -365,31 +366,15 @@ class Threads:
         pass
 
 
-def device_fence(dev_index, fake):
+def device_fence(dev_index):
     """torch.cuda.synchronize() on the worker's GPU: the library's calls already return after their stream has drained,
     this is the contract's belt to those braces"""
-    if fake:
-        return
     import torch
     if torch.cuda.is_available():
         torch.cuda.synchronize(dev_index)
 
 
-def device_class():
-    """capi.Device - or, for the CPU tests of this file's N>1 plumbing only, the stand-in named by ECL_BENCH_DEVICE_CLS
-    ("module:Class", same surface; tests/fake_device.py).  Nothing in a normal run sets it."""
-    spec = os.environ.get("ECL_BENCH_DEVICE_CLS")
-    if not spec:
-        from ecloop_amd.capi import Device
-        return Device, False
-    import importlib
-    mod, cls = spec.split(":")
-    return getattr(importlib.import_module(mod), cls), True
-
-
-def visible_gpus(fake):
-    if fake:
-        return 1 << 20
+def visible_gpus():
     from ecloop_amd import capi
     return max(int(capi.load().ecl_hip_device_count()), 0)
 
@@ -427,12 +412,12 @@ def bench_mul(args, sync, dev_index, emit):
     for _ in range(max(args.warmup, 1)):
         step()
     ks.dev.reset_timing()
-    device_fence(dev_index, False)
+    device_fence(dev_index)
     sync.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    device_fence(dev_index, False)
+    device_fence(dev_index)
     sync.barrier()
     dt = sync.allmax(time.perf_counter() - t0)
     ms, calls, nsc = ks.dev.mul_timing()
@@ -466,7 +451,6 @@ def bench_add(args, sync, dev_index, emit, t_process):
     """one worker (rank or device thread): its shard of every leg on GPU `dev_index`; worker 0 reports"""
     from ecloop_amd.engine import Filter, KeySearch, calc_priv, shard
     rank, world = sync.rank, sync.world
-    Dev, fake = device_class()
     nkeys = 1 << args.keys_log2
     # per-worker scan of each leg: strong = shard `rank` of the one range, weak = the worker's own range
     legs = {"strong": (RANGE_A + shard(nkeys, rank, world)[0], shard(nkeys, rank, world)[1]),
@@ -477,7 +461,7 @@ def bench_add(args, sync, dev_index, emit, t_process):
     headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
     ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=dev_index, a33="c" in args.addr, a65="u" in args.addr,
                    endo=args.endo, verify=True,
-                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes, device_cls=Dev)
+                   launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
     size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.filter_n, ranges=world, cuda_index=dev_index)
     words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
     for m in order:  # walk buffers allocated with the inputs, outside the timed region
@@ -494,12 +478,12 @@ def bench_add(args, sync, dev_index, emit, t_process):
         for _ in range(warmup):
             step()
         ks.dev.reset_timing()
-        device_fence(dev_index, fake)
+        device_fence(dev_index)
         sync.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        device_fence(dev_index, fake)
+        device_fence(dev_index)
         mine_dt = time.perf_counter() - t0
         sync.barrier()
         dt = sync.allmax(time.perf_counter() - t0)
@@ -538,7 +522,7 @@ def bench_add(args, sync, dev_index, emit, t_process):
         "metric": "Mkeys/sec (add, addr33)" if headline else f"Mkeys/sec (add -a {args.addr}{' -endo' if args.endo else ''})",
         "value": round(main_leg["value"], 2), "unit": "Mkeys/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_leg["ms_per_step"], 3),
-        "higher_is_better": True, "scaling": order[0], "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "higher_is_better": True, "scaling": order[0], "vs_baseline": None, "dtype": "u32", "data": DATA,
         "config": {"workload": f"add addr33, {what}, .blf bloom ({args.filter_n} entries, {size * 8 / 1e6:.0f} MB) resident in HBM",
                    "keys_per_gpu_per_step": per_gpu, "parallelism": f"range-sharded x{world}, no collective", "launcher": sync.kind,
                    "found_per_step": sum(x["found_per_step"] for x in main_leg["shards"]),
@@ -556,9 +540,7 @@ def bench_add(args, sync, dev_index, emit, t_process):
         res["config"]["hashes_per_key"] = hashes_per_key
         res["roofline"] = {"bound": "valu-int32", "note": "non-headline variant: no PMC profile of this kernel is loaded", "ms_per_launch": round(ms_launch, 3),
                            "keys_per_launch": int(keys_per_launch), "hash160_per_s_G": round(main_leg["value"] * hashes_per_key / 1e3, 2)}
-    if fake:
-        res["data"] = "synthetic (TEST STAND-IN for the device: not a measurement)"
-    if world == 1 and not args.no_cpu and headline and not fake:
+    if world == 1 and not args.no_cpu and headline:
         cb, (log2n, cpu_lines) = cpu_baseline(words)
         res["cpu_baseline"] = cb
         if log2n <= args.keys_log2:
@@ -606,16 +588,14 @@ def main():
     if launched and args.gpus is not None and args.gpus != world:
         raise SystemExit(f"[bench] --gpus {args.gpus} contradicts the launcher's WORLD_SIZE {world}")
     local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
-    _, fake = device_class()
-    if not fake:
-        # torch's HIP runtime (its own copy in the wheel) must come up BEFORE libecloop_hip's (/opt/rocm): the other way
-        # round torch finds "no ROCm-capable device" - and torch is what fills multi-GB synthetic filters on the device
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-            if local < torch.cuda.device_count():  # otherwise: refused below (or folded onto the GPUs that exist by the test hook)
-                torch.cuda.set_device(local)
-    if not fake and local == 0:
+    # torch's HIP runtime (its own copy in the wheel) must come up BEFORE libecloop_hip's (/opt/rocm): the other way
+    # round torch finds "no ROCm-capable device" - and torch is what fills multi-GB synthetic filters on the device
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+        if local < torch.cuda.device_count():  # otherwise: refused below (or folded onto the GPUs that exist by the test hook)
+            torch.cuda.set_device(local)
+    if local == 0:
         from ecloop_amd.build import build_library
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing
     # test hook (not used by the driver): ECL_BENCH_SHARE_GPU=1 lets several workers run on the GPUs that exist
@@ -634,7 +614,7 @@ def main():
     if launched and world > 1:
         sync = Ranks(args.control, local)  # rendezvous first: rank 0 has built the library by the time the others load it
         sync.barrier()
-        have = visible_gpus(fake)
+        have = visible_gpus()
         if have < world and not share:
             raise SystemExit(f"[bench] {world} ranks but {have} GPU(s) visible: refusing to report n_gpus={world} (one rank per GPU)")
         try:
@@ -642,7 +622,7 @@ def main():
         finally:
             sync.close()
         return
-    have = visible_gpus(fake)
+    have = visible_gpus()
     if have < world and not share:
         raise SystemExit(f"[bench] --gpus {world} but {have} GPU(s) visible: refusing to run (one device thread per GPU)")
     if world == 1:

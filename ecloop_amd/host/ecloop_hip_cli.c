@@ -1089,7 +1089,7 @@ static void *mul_reader(void *arg) {
 typedef struct {
   u64 (*ks)[4]; size_t cap, n; bool pinned; /* scalars (hex lines, -bin); n = entries of this chunk in either form */
   /* -raw: the chunk's text and its line table (offset | length << 32) instead - the GPU hashes (ecl_hip_mul_batch_raw) */
-  u8 *text; size_t text_cap, text_len; u64 *lines; size_t lines_cap; bool raw_pinned;
+  u8 *text; size_t text_cap, text_len; u64 *lines; size_t lines_cap; bool text_pinned, lines_pinned;
 } scalar_array;
 /* scalar arrays live in page-locked memory so that the GPUs read them by DMA (no staging copy in ecl_hip_mul_batch) */
 static void ks_free(const run_t *run, u64 (*ks)[4], bool pinned) {
@@ -1106,22 +1106,27 @@ static void ks_grow(const run_t *run, scalar_array *ar, size_t n) {
   if (!ar->ks) ar->ks = malloc(cap * 32);
   ar->cap = cap;
 }
+/* text and line table are page-locked independently (text_pinned / lines_pinned): one of them falling back to pageable
+   memory leaves the other - and the bytes the scan workers already copied into it - alone */
+static void raw_release(void *p, bool pinned) {
+  if (!p) return;
+  if (pinned) ecl_hip_free_host(p);
+  else free(p);
+}
 static void raw_grow(const run_t *run, scalar_array *ar, size_t text_bytes, size_t nlines) {
-  if (text_bytes > ar->text_cap) {
-    if (ar->text) { if (ar->raw_pinned) ecl_hip_free_host(ar->text); else free(ar->text); }
+  if (text_bytes > ar->text_cap) { /* only ever called for a chunk whose text has not been copied in yet */
+    raw_release(ar->text, ar->text_pinned);
     ar->text_cap = text_bytes + text_bytes / 8 + 4096;
     ar->text = run->parse_only ? NULL : ecl_hip_alloc_host(ar->text_cap);
-    ar->raw_pinned = ar->text != NULL;
+    ar->text_pinned = ar->text != NULL;
     if (!ar->text) ar->text = malloc(ar->text_cap);
   }
   if (nlines > ar->lines_cap) {
-    if (ar->lines) { if (ar->raw_pinned) ecl_hip_free_host(ar->lines); else free(ar->lines); }
+    raw_release(ar->lines, ar->lines_pinned);
     ar->lines_cap = nlines + nlines / 8 + 1024;
-    ar->lines = ar->raw_pinned ? ecl_hip_alloc_host(ar->lines_cap * 8) : NULL;
-    if (!ar->lines) { /* text pageable (parse_only) or the allocation failed: both pageable */
-      if (ar->raw_pinned) { u8 *t = malloc(ar->text_cap); ecl_hip_free_host(ar->text); ar->text = t, ar->raw_pinned = false; }
-      ar->lines = malloc(ar->lines_cap * 8);
-    }
+    ar->lines = run->parse_only ? NULL : ecl_hip_alloc_host(ar->lines_cap * 8);
+    ar->lines_pinned = ar->lines != NULL;
+    if (!ar->lines) ar->lines = malloc(ar->lines_cap * 8);
   }
 }
 /* The arrays of a run are allocated while the devices come up (bring_up starts mul_prealloc beside the device threads):
@@ -1332,8 +1337,7 @@ static void cmd_mul(run_t *run) {
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
   for (int i = 0; i < sq.narr; ++i) {
     ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
-    if (sq.arr[i].raw_pinned) ecl_hip_free_host(sq.arr[i].text), ecl_hip_free_host(sq.arr[i].lines);
-    else free(sq.arr[i].text), free(sq.arr[i].lines);
+    raw_release(sq.arr[i].text, sq.arr[i].text_pinned), raw_release(sq.arr[i].lines, sq.arr[i].lines_pinned);
   }
   for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp), free(rs[i].tmp);
   if (!run->parse_only) report_close(&run->rep);
@@ -1398,8 +1402,7 @@ static void window_print_bound(const sc *v, u32 offs, u32 size, bool colour) {
    stops after the first window if that window is the whole range, otherwise runs until interrupted
    (ECLOOP_HIP_RND_WINDOWS=N, for tests and timing runs, stops after N windows). */
 static void cmd_rnd(run_t *run) {
-  report_t *rep = &run->rep;
-  if (run->ord_offs + run->ord_size > 255) run->ord_offs = 255 - run->ord_size;
+  report_t *rep = &run->rep; /* (the window was clamped to 255 bits where it was parsed: window_from_option) */
   printf("[RANDOM MODE] offs: %d ~ bits: %d\n\n", run->ord_offs, run->ord_size);
   report_restart_clock(rep);
   const sc A = run->range_s, B = run->range_e;
@@ -1550,7 +1553,11 @@ static void range_from_option(const char *text, sc *first, sc *last) {
 }
 /* -d offs:size (load_offs_size, main.c:703-746).  size: 20..64, default min(32, max(20, bits of B)); offs: at most 255 and
    at most max(1, max(20, bits of B) - default size) - so that a window stays inside the range; `rnd` without -d draws
-   the offset at random. */
+   the offset at random.  `rnd` also keeps offs + size within 255 bits (main.c:620) - here, before anything is derived from
+   the offset (the stride 2^offs, the device contexts), as the reference does before ctx_precompute_gpoints (main.c:624). */
+static void window_clamp_rnd(run_t *run) {
+  if (run->cmd == CMD_RND && run->ord_offs + run->ord_size > 255) run->ord_offs = 255 - run->ord_size;
+}
 static void window_from_option(run_t *run) {
   const u32 lo_size = 20, hi_size = 64;
   const u32 span_bits = sc_bitlen(&run->range_e) > lo_size ? sc_bitlen(&run->range_e) : lo_size;
@@ -1560,6 +1567,7 @@ static void window_from_option(run_t *run) {
   run->ord_offs = 0, run->ord_size = usual;
   if (!text) {
     if (run->cmd == CMD_RND) run->ord_offs = (u32)(random_u64(run->seeded) % offs_cap);
+    window_clamp_rnd(run);
     return;
   }
   const char *colon = strchr(text, ':');
@@ -1568,6 +1576,7 @@ static void window_from_option(run_t *run) {
   if (offs > 255) { fprintf(stderr, "invalid offset, max is 255\n"); exit(1); }
   if (size < lo_size || size > hi_size) { fprintf(stderr, "invalid size, min is %d and max is %d\n", lo_size, hi_size); exit(1); }
   run->ord_offs = offs < offs_cap ? offs : offs_cap, run->ord_size = size;
+  window_clamp_rnd(run);
 }
 static void usage(const char *prog) { /* the reference's help text (main.c:750-772) with this program's -t and extras */
   static const char *const TEXT[] = {
@@ -1871,7 +1880,8 @@ int main(int argc, const char **argv) {
     return 0;
   }
   const bool plan_only = !strcmp(verb, "plan"); /* hidden: the job arithmetic of `add` / `rnd`, the context -> GPU map; no GPU */
-  run.cmd = !strcmp(verb, "add") || plan_only ? CMD_ADD : !strcmp(verb, "mul") ? CMD_MUL : !strcmp(verb, "rnd") ? CMD_RND : CMD_NIL;
+  run.cmd = plan_only ? (o->rnd_jobs ? CMD_RND : CMD_ADD) /* `plan -rnd`: rnd's window rules (offset drawn or clamped) and full-size jobs */
+            : !strcmp(verb, "add") ? CMD_ADD : !strcmp(verb, "mul") ? CMD_MUL : !strcmp(verb, "rnd") ? CMD_RND : CMD_NIL;
   if (run.cmd == CMD_NIL) {
     if (o->version) printf("ecloop-hip v%s\n", VERSION);
     else usage(argv[0]);
@@ -1905,6 +1915,7 @@ int main(int argc, const char **argv) {
     }
     scan_t sn;
     scan_plan(&run, run.range_s, run.range_e, o->rnd_jobs, &sn);
+    printf("stride_bits %u ", sc_bitlen(&run.stride_k) - 1);
     printf("ord_offs %u ord_size %u hashed %016llx%016llx%016llx%016llx status_total %llu chunk %llu\n", run.ord_offs, run.ord_size,
            (unsigned long long)sn.hashed.w[3], (unsigned long long)sn.hashed.w[2], (unsigned long long)sn.hashed.w[1],
            (unsigned long long)sn.hashed.w[0], (unsigned long long)sn.status_total, (unsigned long long)sn.chunk);

@@ -98,9 +98,10 @@ int ecl_hip_get_bloom(ecl_hip *h, uint64_t *bits, uint64_t nwords);
    and colliding hashes (the bits are those of ecl_hip_bloom_insert). */
 int ecl_hip_bloom_insert_count(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n, uint64_t *added);
 
-/* load_filter's list preparation (main.c:96-131: qsort by compare_160, duplicates stay; here they are dropped) on the device:
+/* load_filter's list preparation (main.c:112-124: qsort by compare_160, then duplicates removed - the same here) on the device:
    sorts the n entries of h160 in place into compare_160 order (addr.c:18-26: word by word), removes duplicates, *kept =
-   entries left at the front of the array.  n < 2^31.  10^7 entries: 13 s of qsort + bit setting on the host, well under a
+   entries left at the front of the array.  (The radix passes and the scan are hipCUB calls - library code, off the hot
+   path: a list is prepared once per run.)  n < 2^31.  10^7 entries: 13 s of qsort + bit setting on the host, well under a
    second here (the bits: ecl_hip_set_bloom of a zero filter + ecl_hip_bloom_insert + ecl_hip_get_bloom). */
 int ecl_hip_sort_list(ecl_hip *h, uint32_t (*h160)[5], uint64_t n, uint64_t *kept);
 
@@ -128,7 +129,7 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
 
 /* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index.
    The fixed-base window table of ec_gtable_mul (lib/ecc.c:876-929) is built on the device at a window width sized for
-   HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB): a context starts on 20 bits (13 rows, 872 MB, a few
+   HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB): a context starts on 20 bits (13 rows, 12 * (2^20 - 1) + 65535 points of 64 bytes = 809 MB, a few
    ms) and moves to 22 bits (12 rows, 3.0 GB, ~50 ms: 12 additions per scalar instead of 19) once it has multiplied 2^30
    scalars, which is when the wider table has paid for its build.  A table is checked against the double-and-add kernel
    on sample slots before use (ECL_E_SELFTEST on a mismatch), shared between the contexts of a device in the process

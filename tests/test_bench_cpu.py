@@ -1,5 +1,6 @@
 """bench.py's N>1 plumbing on the CPU: `--gpus 2` with NO launcher (two device threads in one process) and under
-torch.distributed.run (two ranks, gloo rendezvous), the GPU replaced by tests/fake_device.py.  What is under test is
+torch.distributed.run (two ranks, gloo rendezvous), the GPU replaced by tests/fake_device.py through the launcher
+tests/bench_on_fake_device.py (bench.py has no test hook of its own).  What is under test is
 what the driver's scaling run depends on: the flag is honoured (n_gpus: 2, never a silent 1), the shards tile the
 range, every worker checks its planted keys, MAX-over-workers timing and the gather of the per-GPU shard records.
 The numbers in the line are meaningless here and the line says so (`data`)."""
@@ -11,8 +12,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENV = dict(os.environ, ECL_BENCH_DEVICE_CLS="fake_device:FakeDevice",
-           PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+ENV = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+BENCH = os.path.join(ROOT, "tests", "bench_on_fake_device.py")  # swaps capi.Device for the oracle-backed stand-in, then bench.main()
 SMALL = ["--keys-log2", "15", "--filter-n", "2000", "--steps", "2", "--warmup", "1", "--launch-log2", "14"]
 
 
@@ -37,7 +38,7 @@ def check_two_gpu_line(r, launcher):
 
 @pytest.mark.timeout(600)
 def test_gpus_2_without_a_launcher_runs_two_device_threads():
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, stdout=subprocess.PIPE,
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, timeout=580, cwd=ROOT, env=ENV)
     check_two_gpu_line(last_json(pr), "in-process device threads")
 
@@ -50,26 +51,25 @@ def test_gpus_2_under_torch_distributed_run():
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
+           "--master-port", str(port), BENCH, "--gpus", "2"] + SMALL
     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=580, cwd=ROOT, env=ENV)
     check_two_gpu_line(last_json(pr), "torch.distributed.run")
 
 
 def test_single_worker_line_and_contradicting_flags():
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--no-cpu"], stdout=subprocess.PIPE,
+    pr = subprocess.run([sys.executable, BENCH] + SMALL + ["--no-cpu"], stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, timeout=580, cwd=ROOT, env=ENV)
     r = last_json(pr)
     assert r["n_gpus"] == 1 and r["config"]["shards"][0]["keys_per_step"] == 1 << 15 and "weak_scaling" not in r
     # a launcher's WORLD_SIZE that contradicts --gpus is an error, not a guess
     env = dict(ENV, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
-    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + SMALL, stdout=subprocess.PIPE,
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "4"] + SMALL, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, timeout=120, cwd=ROOT, env=env)
     assert pr.returncode != 0 and b"contradicts" in pr.stderr
 
 
 def test_more_gpus_than_visible_is_refused():
     """with the real library and no GPU in this container (or fewer than asked for anywhere): loud failure"""
-    env = {k: v for k, v in ENV.items() if k != "ECL_BENCH_DEVICE_CLS"}
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--no-cpu"] + SMALL, stdout=subprocess.PIPE,
-                        stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=env)
+                        stderr=subprocess.PIPE, timeout=300, cwd=ROOT, env=ENV)
     assert pr.returncode != 0 and b"GPU(s) visible" in pr.stderr and not pr.stdout.strip()

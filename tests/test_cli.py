@@ -216,14 +216,20 @@ def test_rnd_window_is_an_add_over_the_printed_bounds(cli, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1500)
 @pytest.mark.parametrize("size,mode,nwin", [(20, "ones", 1), (32, "a", 2)])
-def test_rnd_at_configs3_shape_equals_add_on_the_printed_masks(cli, tmp_path, size, mode, nwin):
+def test_rnd_at_configs3_shape_against_the_oracle_on_the_printed_masks(cli, tmp_path, size, mode, nwin):
     """BASELINE configs[3]: `rnd -d 128:32` on a 168-bit range.  Every window the generator prints (two 64-digit masks,
-    main.c:593-617) must hash exactly the keys `add -r s:e -d 128:<size>` hashes on those bounds: the found sets are
-    compared window by window - all-ones filter (every key a hit) for 2^21-key windows, a half-dense synthetic filter
-    (~4096 false positives per 2^32 keys) for the full 2^32-key window of the named config."""
+    main.c:593-617) must hash exactly the keys the ORACLE's cmd_add workers hash on those bounds at stride 2^128 with
+    cmd_rnd's full-size jobs (orc.add_range(..., offs=128, rnd=True): the restatement of main.c:405-454,619-662 that
+    tests/test_oracle_golden.py pins to the windows the reference itself drew).  All-ones filter (every key a hit) for the
+    2^21-key window; for the named config's real window size a half-dense synthetic filter (~4096 false positives per
+    2^32 keys): the first window is compared in full - 2^32 keys through the oracle, a minute or two on the box's host
+    cores - and of the second one the first 2^28 keys (a shorter oracle run over a prefix of the printed window)."""
+    import orc
+    words = np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(70001, seed=23, mode=mode)
     blf = str(tmp_path / "f.blf")
-    write_blf(blf, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(70001, seed=23, mode=mode))
+    write_blf(blf, words)
     lo, hi = (1 << 167) + 0x1234567, (1 << 168) - 0x7654321
     out = str(tmp_path / "rnd.txt")
     env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS=str(nwin), ECLOOP_HIP_STATS="1")
@@ -234,23 +240,32 @@ def test_rnd_at_configs3_shape_equals_add_on_the_printed_masks(cli, tmp_path, si
     assert f"[RANDOM MODE] offs: 128 ~ bits: {size}" in text
     masks = [int(l.replace(" ", ""), 16) for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
     assert len(masks) == 2 * nwin
+    _, wins = rnd_windows(text)
     rnd_lines = sorted(l.rstrip("\n") for l in open(out))
-    want = []
+    flt = orc.OrcFilter(bloom_words=words)
+    threads = min(os.cpu_count() or 8, 128)
+    span = max(1 << size, 1 << 21)  # keys a window hashes: cmd_rnd runs whole 2^21-key jobs (main.c:624)
+    covered = 0
     for w in range(nwin):
         s, e = masks[2 * w], masks[2 * w + 1]
         field = ((1 << size) - 1) << 128
         assert lo <= s < e <= hi
         if s != lo and e != hi:  # not clipped to the range (main.c:586-589): bits offs..offs+size-1 cleared / set
             assert s & field == 0 and e & field == field and s | field == e
-        lines, status, _ = run(cli, ["add", "-f", blf, "-r", f"{s:x}:{e:x}", "-d", f"128:{size}"], out=str(tmp_path / f"add{w}.txt"))
-        assert counts(status)[1] == max(1 << size, 1 << 21)
-        want += lines
-    assert rnd_lines == sorted(want)
-    assert len(rnd_lines) == (nwin << 21 if mode == "ones" else len(rnd_lines)) and len(rnd_lines) > 1000
-    # every key of a window differs from its start only in the window's bit field
-    for l in rnd_lines[:: max(1, len(rnd_lines) // 500)]:
-        k = int(l.split("\t")[2], 16)
-        assert any((k - masks[2 * w]) % (1 << 128) == 0 and 0 <= (k - masks[2 * w]) >> 128 < 1 << max(size, 21) for w in range(nwin)), hex(k)
+        mine = [l for l in rnd_lines if (int(l.split("\t")[2], 16) - s) % (1 << 128) == 0 and 0 <= (int(l.split("\t")[2], 16) - s) >> 128 < span]
+        if w == 0 or size <= 21:
+            rc, o, n, checked, hashed = orc.add_range(flt, s, e, offs=128, rnd=True, threads=threads, cap=1 << 22)
+            assert rc == 0 and (checked, hashed) == (span, span)
+            assert wins[w][3:] == (n, checked)  # the window's `found / checked` summary line
+            assert mine == sorted(orc.found_lines(o, n))
+            covered += len(mine)
+        else:  # a prefix of the window: its first 2^28 keys (128 whole jobs; the oracle's bounds are inclusive like -r)
+            part = 1 << 28
+            rc, o, n, checked, hashed = orc.add_range(flt, s, s + ((part - 1) << 128), offs=128, rnd=True, threads=threads, cap=1 << 20)
+            assert rc == 0 and hashed == part
+            assert [l for l in mine if (int(l.split("\t")[2], 16) - s) >> 128 < part] == sorted(orc.found_lines(o, n))
+            assert wins[w][4] == span
+    assert covered == (nwin << 21 if mode == "ones" else covered) and covered > 1000
     assert "set-ups" in text
 
 
@@ -637,6 +652,22 @@ def test_scan_plan_matches_the_oracles_job_loop(cli):
     assert out[out.index("status_total") + 1] == str(6 * 16777216)
     out = subprocess.run([cli, "plan"], stdout=subprocess.PIPE, check=True).stdout.decode().split()
     assert out[out.index("status_total") + 1] == "0" and int(out[out.index("hashed") + 1], 16) > 1 << 255
+
+
+def test_rnd_window_wider_than_255_bits_moves_the_stride_with_the_offset(cli):
+    """`rnd -d 200:64` on a 256-bit range: load_offs_size lets the offset through (max_offs = 224), cmd_rnd lowers it to
+    255 - 64 = 191 (main.c:620) BEFORE ctx_precompute_gpoints derives stride_k = 2^191 from it (main.c:222,624).  The stride
+    the walk uses and the offset of the window mask must be the same number (round-3 advisor finding: the clamp came after
+    the stride had been fixed at 2^200, so 511 of 512 keys of the window were never visited); `add` is not clamped."""
+    def plan(*a):
+        out = subprocess.run([cli, "plan"] + list(a), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+        return dict(zip(out[::2], out[1::2]))
+    top = "%x:%x" % (1 << 255, (1 << 256) - (1 << 130))  # below n
+    for offs, size, want in ((200, 64, 191), (224, 64, 191), (224, 40, 215), (100, 64, 100), (192, 63, 192), (193, 63, 192)):
+        got = plan("-rnd", "-r", top, "-d", f"{offs}:{size}")
+        assert (int(got["ord_offs"]), int(got["stride_bits"]), int(got["ord_size"])) == (want, want, size), (offs, size, got)
+    got = plan("-r", top, "-d", "224:64")
+    assert (int(got["ord_offs"]), int(got["stride_bits"])) == (224, 224)
 
 
 def test_context_to_gpu_map(cli):

@@ -3,7 +3,9 @@ profiles/r<NN>_roofline.json (VALU instructions per key, HBM bytes, clock - meas
 The check is static: the instruction mix of k_add<addr33> in the assembly of the freshly built library
 (tools/isa_mix.py) against the fingerprint stored in the profile, 1 % tolerance per field.  A drift is reported as a
 WARNING here (and as `profile.matches_build: false` + a STALE note in bench.py's line): an ordinary kernel change must
-not turn the CPU suite red until somebody has been to the GPU box - tools/collect_profiles.sh is the remedy.  What
+not turn the CPU suite red until somebody has been to the GPU box - tools/collect_profiles.sh is the remedy.  With
+ECL_REQUIRE_FRESH_PROFILES=1 (collection / release runs) the drift is a failure, and on the GPU box
+tests/test_gpu_bench.py fails when the line bench.py prints says `matches_build: false`.  What
 stays a hard failure is structural: the loop nest the per-key estimate relies on, and no scratch (spill) traffic in
 the per-key loops.  Needs hipcc (or the assembly a previous build kept); skipped without either."""
 import glob
@@ -37,7 +39,12 @@ def test_static_mix_of_the_built_kernel_matches_the_profile():
     fp, want = a["fingerprint"], prof["fingerprint"]
     stale = [f"{k}: built {fp.get(k)} vs {v}" for k, v in want.items() if k in fp and abs(fp[k] - v) > max(0.01 * v, 1)]
     if stale:
-        warnings.warn(f"{name} was collected on another build of k_add ({'; '.join(stale)}): re-run tools/collect_profiles.sh")
+        msg = f"{name} was collected on another build of k_add ({'; '.join(stale)}): re-run tools/collect_profiles.sh"
+        # collection / release runs (tools/collect_profiles.sh, the end-of-round check) set ECL_REQUIRE_FRESH_PROFILES=1:
+        # there a profile of another build is a failure; tests/test_gpu_bench.py asserts the same on the GPU box
+        # (`roofline.profile.matches_build` of the line bench.py prints)
+        assert os.environ.get("ECL_REQUIRE_FRESH_PROFILES") != "1", msg
+        warnings.warn(msg)
     # the loop nest the estimate relies on is the one add_kernel.h describes
     assert a["which_loop"]["valu"] > 2500 and a["table_loop"]["mad64"] >= 162 and a["prefix_loop"]["mad64"] >= 81
     # spill traffic stays out of the per-key loops: scratch instructions only in the once-per-group launch loop
