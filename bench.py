@@ -51,6 +51,7 @@ PEAK_4CYCLE = 256 * 4 * 16 * 2.4e9 / 1e12
 PEAK_2CYCLE = 2 * PEAK_4CYCLE
 HBM_PEAK_GBS = 8000.0
 DATA = "synthetic"  # what the line's `data` field says
+SETUP = {}  # where the process spent its time before the first timed step (config.process_setup)
 ALGO_BYTES_PER_KEY = 18 + 18 + 1.59 * 8  # chain element (36 B) written + read per two keys; 1.59 probes x 8 B
 
 
@@ -424,7 +425,7 @@ def bench_mul(args, sync, dev_index, emit):
     if rank != 0:
         return
     hashes = len(addr)
-    prof, path = load_profile("mul")
+    prof, path = load_profile("roofline_mul")
     res = {"metric": f"M scalars/sec (mul -a {addr})", "value": round(n * world * args.steps / dt / 1e6, 2), "unit": "Mscalars/s", "n_gpus": world,
            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -459,13 +460,19 @@ def bench_add(args, sync, dev_index, emit, t_process):
 
     # --- inputs -> HBM (untimed)
     headline = args.addr == "c" and not args.endo and args.filter_n == FILTER_N
+    t0 = time.perf_counter()
     ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=dev_index, a33="c" in args.addr, a65="u" in args.addr,
                    endo=args.endo, verify=True,
                    launch_keys=1 << args.launch_log2, half_group=args.half_group, max_lanes=args.lanes)
+    setup = dict(SETUP, context_open_and_selftest_s=round(time.perf_counter() - t0, 2))  # HIP init, streams, the device code's self-test
+    t0 = time.perf_counter()
     size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.filter_n, ranges=world, cuda_index=dev_index)
     words = ks.dev.get_bloom(size) if (rank == 0 and world == 1 and not args.no_cpu and headline) else None
+    setup["filter_build_s"] = round(time.perf_counter() - t0, 2)
+    t0 = time.perf_counter()
     for m in order:  # walk buffers allocated with the inputs, outside the timed region
         ks.dev.reserve(min(legs[m][1], 1 << args.launch_log2))
+    setup["reserve_walk_buffers_s"] = round(time.perf_counter() - t0, 2)
     t_setup = time.perf_counter() - t_process
 
     def run_leg(mode, steps, warmup):
@@ -528,7 +535,7 @@ def bench_add(args, sync, dev_index, emit, t_process):
                    "found_per_step": sum(x["found_per_step"] for x in main_leg["shards"]),
                    "planted_checked": sum(x["planted_checked"] for x in main_leg["shards"]),
                    "setup_ms_per_step_on_device": round(main_leg["setup_ms"] / args.steps, 3), "process_setup_s": round(t_setup, 2),
-                   "shards": main_leg["shards"]},
+                   "process_setup": setup, "shards": main_leg["shards"]},
         "roofline": add_roofline(ms_launch, keys_per_launch),
     }
     for m in order[1:]:
@@ -549,7 +556,312 @@ def bench_add(args, sync, dev_index, emit, t_process):
             if gpu_lines != cpu_lines:
                 emit(res)
                 raise SystemExit(f"[bench] FOUND LIST MISMATCH on the CPU sample: gpu {len(gpu_lines)} lines, cpu {len(cpu_lines)} lines")
+    if world == 1 and headline and not args.no_secondary and args.keys_log2 == 32:
+        res["secondary"] = secondary_legs(args, dev_index)  # configs[2], [3], [4] in the same run; a failed check aborts
     emit(res)
+
+
+
+# ----------------------------------------------------------------------------------------------- secondary legs (N = 1)
+# BASELINE.json's other configs, measured in the same run as the headline and reported under `secondary` (the headline
+# fields are untouched): cfg2 = configs[2] on one GPU (add -a cu -endo, ~6 GB .blf), cfg3 = configs[3] (rnd -d 128:32
+# windows through the C host program), cfg4 = configs[4] (mul: scalars through ecl_hip_mul_batch and hex lines through
+# the host program's stdin).  Each leg checks what it found: planted keys must be there, and the found list over a
+# bounded sample must equal the oracle's (tests/orc.py over oracle/liborc.so: the checker, never the thing timed).
+# A failed check aborts the run like the headline's.
+
+
+def _orc():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    import orc
+    return orc
+
+
+def _roofline_from(kind, ops_key, rate_per_s, what):
+    """roofline object of a secondary kernel: VALU lane-ops per unit from profiles/rNN_roofline_<kind>.json x the rate
+    measured here, against the same 2-clock VALU peak as the headline"""
+    prof, path = load_profile("roofline_" + kind)
+    r = {"bound": "valu-int32", "kernel": what, "unit": "T lane-ops/s", "peak": round(PEAK_2CYCLE, 2)}
+    ops = (prof or {}).get("derived", {}).get(ops_key)
+    if not ops:
+        r.update({"achieved": None, "frac": None, "profile": None, "note": "no PMC profile of this kernel under profiles/"})
+        return r
+    from ecloop_amd.build import source_sha256
+    ach = ops * rate_per_s / 1e12
+    r.update({"achieved": round(ach, 3), "frac": round(ach / PEAK_2CYCLE, 4), ops_key: round(ops, 1),
+              "profile": {"file": path, "source_sha256_matches": prof.get("source_sha256") == source_sha256(),
+                          "valu_busy_pct": prof["derived"].get("valu_busy_pct"), "clock_ghz": prof["derived"].get("clock_ghz")}})
+    t = prof.get("traffic") or {}
+    if t.get("bytes_per_unit_reported") is not None:
+        r["traffic_bytes_per_unit_reported"] = round(t["bytes_per_unit_reported"], 1)
+    return r
+
+
+def leg_cu_endo(args, dev_index):
+    """configs[2] on one GPU: add -a cu -endo (12 hash160 per key), filter of 1.1e9 entries (5.9 GB) resident in HBM"""
+    from ecloop_amd.engine import Filter, KeySearch, calc_priv
+    orc = _orc()
+    nkeys, sample = 1 << args.cfg2_keys_log2, 1 << 21
+    t0 = time.perf_counter()
+    ks = KeySearch(Filter(np.zeros(1, dtype=np.uint64)), device=dev_index, a33=True, a65=True, endo=True, verify=True)
+    size, planted_offs, _ = build_filter(ks.dev, RANGE_A, nkeys, args.cfg2_filter_n, cuda_index=dev_index)
+    inside = [RANGE_A + 1000 + 4099 * i for i in range(16)]  # 16 more planted keys inside the oracle sample
+    xs, ys, _ = ks.dev.diag_mulg(inside)
+    h33, h65 = ks.dev.diag_hash160(xs, ys)
+    ks.dev.bloom_insert(h33)
+    ks.dev.bloom_insert(h65)
+    ks.dev.reserve(nkeys)
+    t_setup = time.perf_counter() - t0
+
+    def step():
+        ks.found.clear()
+        ks.add_keys(RANGE_A, nkeys)
+
+    step()
+    ks.dev.reset_timing()
+    device_fence(dev_index)
+    t0 = time.perf_counter()
+    for _ in range(args.cfg2_steps):
+        step()
+    device_fence(dev_index)
+    dt = time.perf_counter() - t0
+    kernel_ms, launches, kkeys = ks.dev.timing()
+    found_pks = {r.pk for r in ks.found}
+    want = [RANGE_A + o for o in planted_offs] + inside
+    missing = [hex(k) for k in want if calc_priv(k, 1, 0, 0) not in found_pks]
+    if missing:
+        raise SystemExit(f"[bench] cfg2: planted keys not found: {missing}")
+    nfound = len(ks.found)
+    # the oracle on a sample of the same range and the same 5.9 GB of filter words (copied back from the device)
+    t0 = time.perf_counter()
+    words = ks.dev.get_bloom(size)
+    ks.found.clear()
+    ks.add_keys(RANGE_A, sample)
+    gpu_lines = sorted(r.line() for r in ks.found)
+    ks.close()
+    threads = min(os.cpu_count() or 1, 64)
+    rc, out, n, _, hashed = orc.add_range(orc.OrcFilter(bloom_words=words, borrow=True), RANGE_A, RANGE_A + sample, a65=True, endo=True,
+                                          verify=False, threads=threads, cap=1 << 16)
+    cpu_lines = sorted(orc.found_lines(out, n))
+    t_check = time.perf_counter() - t0
+    if rc != 0 or hashed != sample or gpu_lines != cpu_lines or len(cpu_lines) < 32:
+        raise SystemExit(f"[bench] cfg2: FOUND LIST MISMATCH on the oracle sample: gpu {len(gpu_lines)} lines, oracle {len(cpu_lines)} (rc {rc}, hashed {hashed})")
+    rate = nkeys * args.cfg2_steps / dt
+    krate = kkeys / (kernel_ms * 1e-3) if kernel_ms else 0.0
+    return {"metric": "Mkeys/sec (add -a cu -endo)", "value": round(rate / 1e6, 2), "unit": "Mkeys/s", "hash160_per_s_G": round(rate * 12 / 1e9, 2),
+            "steps": args.cfg2_steps, "ms_per_step": round(dt / args.cfg2_steps * 1e3, 3),
+            "config": {"workload": f"add -a cu -endo, 2^{args.cfg2_keys_log2} contiguous keys from 0x{RANGE_A:x} per step, .blf of {args.cfg2_filter_n} entries "
+                                   f"({size * 8 / 1e6:.0f} MB, random words at the design density) resident in HBM, 1 GPU (configs[2]'s per-GPU shard shape)",
+                       "hashes_per_key": 12, "found_per_step": nfound, "planted_checked": len(want),
+                       "oracle_sample": f"first 2^21 keys (12 hash160 each) on {threads} host threads against the same filter words: {len(cpu_lines)} lines, equal",
+                       "found_list_matches_oracle_on_sample": True, "setup_s": round(t_setup, 1), "check_s": round(t_check, 1)},
+            "roofline": dict(_roofline_from("cu_endo", "valu_lane_ops_per_key", krate, "k_add<addr33,addr65,endo>"),
+                             ms_per_launch=round(kernel_ms / max(launches, 1), 3), keys_per_launch=int(kkeys / max(launches, 1)),
+                             kernel_mkeys_s=round(krate / 1e6, 2))}
+
+
+def secondary_filter(dev_index, scalars_to_plant):
+    """the 56 MB filter of the cfg3 / cfg4 legs: random words at density 0.5 (~4100 false positives per 2^32 hash160: enough
+    lines for an oracle sample to mean something) + the hash160s of the given scalars' public keys; -> (words, path of the .blf)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import synth_bloom_words, write_blf
+    from ecloop_amd.capi import Device
+    words = synth_bloom_words(7000003, 41, "a")
+    d = Device(dev_index, a33=True, a65=True)
+    try:
+        d.set_bloom(words)
+        xs, ys, _ = d.diag_mulg(scalars_to_plant)
+        h33, h65 = d.diag_hash160(xs, ys)
+        d.bloom_insert(h33)
+        d.bloom_insert(h65)
+        words = d.get_bloom(len(words))
+    finally:
+        d.close()
+    tmp = tempfile.mkdtemp(prefix="eclbench2")
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, tmp, ignore_errors=True)
+    path = os.path.join(tmp, "secondary.blf")
+    write_blf(path, words)
+    return words, path, tmp
+
+
+def _status_of(stderr_bytes):
+    status = stderr_bytes.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
+    m = re.search(r"([\d.]+)s ~ ([\d.]+) Mkeys/s ~ ([\d,]+) / ([\d,]+)", status)
+    if not m:
+        raise SystemExit(f"[bench] cannot read the host program's status line: {status!r}")
+    return float(m.group(1)), float(m.group(2)), int(m.group(3).replace(",", "")), int(m.group(4).replace(",", ""))
+
+
+def leg_rnd(args, words, blf, tmp):
+    """configs[3] on one GPU: `ecloop-hip rnd -d 128:32` - random 2^32-key windows at stride 2^128, a new base point per window"""
+    from ecloop_amd.build import build_host_cli
+    orc = _orc()
+    cli = build_host_cli()
+    lo, hi = (1 << 167) + 0x1234567, (1 << 168) - 0x7654321
+    out = os.path.join(tmp, "rnd.txt")
+    nwin = args.cfg3_windows
+    env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS=str(nwin), ECLOOP_HIP_STATS="1")
+    t0 = time.perf_counter()
+    pr = subprocess.run([cli, "rnd", "-f", blf, "-r", f"{lo:x}:{hi:x}", "-d", "128:32", "-seed", "bench", "-t", "1", "-q", "-o", out],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    wall = time.perf_counter() - t0
+    if pr.returncode != 0:
+        raise SystemExit(f"[bench] cfg3: ecloop-hip rnd failed: {pr.stderr.decode(errors='replace')[-500:]}")
+    text = pr.stdout.decode(errors="replace")
+    secs, mkeys, found, checked = _status_of(pr.stderr)
+    masks = [int(l.replace(" ", ""), 16) for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
+    m = re.search(r"gpu 0: (\d+) launches, ([\d.]+) ms in the search kernel, (\d+) set-ups, ([\d.]+) ms in set-up kernels", text)
+    if len(masks) != 2 * nwin or checked != nwin << 32 or not m:
+        raise SystemExit(f"[bench] cfg3: unexpected output of ecloop-hip rnd ({len(masks)} masks, {checked} checked)")
+    kernel_ms, setup_ms = float(m.group(2)), float(m.group(4))
+    lines = sorted(l.rstrip("\n") for l in open(out))
+    # the oracle over a prefix of every printed window: 2^24 keys at stride 2^128 with cmd_rnd's full-size jobs
+    t0 = time.perf_counter()
+    flt = orc.OrcFilter(bloom_words=words)
+    threads, part, compared = min(os.cpu_count() or 1, 64), 1 << 24, 0
+    for w in range(nwin):
+        s = masks[2 * w]
+        rc, o, n, _, hashed = orc.add_range(flt, s, s + ((part - 1) << 128), offs=128, rnd=True, verify=False, threads=threads, cap=1 << 16)
+        want = sorted(orc.found_lines(o, n))
+        mine = [l for l in lines if (int(l.split("\t")[2], 16) - s) % (1 << 128) == 0 and 0 <= (int(l.split("\t")[2], 16) - s) >> 128 < part]
+        if rc != 0 or hashed != part or mine != want:
+            raise SystemExit(f"[bench] cfg3: FOUND LIST MISMATCH on the oracle sample of window {w}: gpu {len(mine)} lines, oracle {len(want)}")
+        compared += len(want)
+    t_check = time.perf_counter() - t0
+    if compared < 8:
+        raise SystemExit(f"[bench] cfg3: the oracle sample holds only {compared} lines: the check means nothing")
+    return {"metric": "Mkeys/sec (rnd -d 128:32)", "value": mkeys, "unit": "Mkeys/s", "windows": nwin, "seconds_by_status_line": secs,
+            "config": {"workload": f"ecloop-hip rnd -d 128:32 -t 1: {nwin} random windows of 2^32 keys at stride 2^128 on a 168-bit range, 56 MB .blf at density 0.5; "
+                                   "rate = the host program's own status line (set-up of every window included, process start-up not)",
+                       "found": found, "checked": checked, "wall_s_incl_process_start": round(wall, 2),
+                       "device_ms_search_kernel": kernel_ms, "device_ms_window_setup": setup_ms, "setup_share": round(setup_ms / (kernel_ms + setup_ms), 5),
+                       "kernel_mkeys_s": round(checked / (kernel_ms * 1e-3) / 1e6, 2),
+                       "oracle_sample": f"first 2^24 keys of each of the {nwin} printed windows on {threads} host threads: {compared} lines, equal",
+                       "found_list_matches_oracle_on_sample": True, "check_s": round(t_check, 1)}}
+
+
+def leg_mul(args, dev_index, words, blf, tmp, planted):
+    """configs[4]: mul -a cu.  (a) 2^24 seeded scalars per call from page-locked host memory through ecl_hip_mul_batch;
+    (b) 2^26 64-hex-digit lines through the host program's stdin (the reference's input format)."""
+    import ctypes as C
+    from ecloop_amd.build import build_host_cli
+    from ecloop_amd.engine import Filter, KeySearch
+    orc = _orc()
+    n, nsample = 1 << args.cfg4_log2, 1 << 12
+    rng = np.random.default_rng(4242)
+    scal = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    for i, k in enumerate(planted):  # the planted scalars sit inside the oracle sample
+        scal[17 * i + 5] = [(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    ks = KeySearch(Filter(words), device=dev_index, a33=True, a65=True, verify=False)
+    lib, h = ks.dev.lib, ks.dev.h
+    if lib.ecl_hip_pin_host(scal.ctypes.data, scal.nbytes) != 0:
+        raise SystemExit("[bench] cfg4: cannot pin the scalar array")
+    cap = 1 << 12
+    out = np.zeros(cap, dtype=np.dtype([("key_offset", "<u8"), ("h160", "<u4", (5,)), ("endo", "u1"), ("compressed", "u1"), ("pad", "u1", (2,))]))
+    cnt = C.c_uint32()
+    ks.dev.set_mul_window(args.mul_window)
+
+    def step():
+        rc = lib.ecl_hip_mul_batch(h, scal.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
+        if rc != 0:
+            raise SystemExit(f"[bench] cfg4: ecl_hip_mul_batch failed: {rc}")
+
+    t0 = time.perf_counter()
+    step()  # builds the table
+    t_first = time.perf_counter() - t0
+    step()
+    ks.dev.reset_timing()
+    device_fence(dev_index)
+    t0 = time.perf_counter()
+    for _ in range(args.cfg4_steps):
+        step()
+    device_fence(dev_index)
+    dt = time.perf_counter() - t0
+    ms, calls, nsc = ks.dev.mul_timing()
+    wbits = ks.dev.mul_window()
+    recs = out[: cnt.value]
+
+    def line(label, h160, k):
+        return "%s\t%s\t%064x" % (label, "".join("%08x" % int(w) for w in h160), k)
+
+    val = lambda row: sum(int(row[j]) << (64 * j) for j in range(4))
+    gpu_lines = sorted(line("addr33" if r["compressed"] else "addr65", r["h160"], val(scal[int(r["key_offset"])])) for r in recs if r["key_offset"] < nsample)
+    rc, o, no = orc.mul_batch(orc.OrcFilter(bloom_words=words), [val(scal[i]) for i in range(nsample)], a33=True, a65=True)
+    cpu_lines = sorted(orc.found_lines(o, no))
+    lib.ecl_hip_unpin_host(scal.ctypes.data)
+    ks.close()
+    if rc != 0 or gpu_lines != cpu_lines or len(cpu_lines) < 2 * len(planted):
+        raise SystemExit(f"[bench] cfg4: FOUND LIST MISMATCH on the oracle sample: gpu {len(gpu_lines)} lines, oracle {len(cpu_lines)}")
+    drate = nsc / (ms * 1e-3) if ms else 0.0
+    api = {"metric": "M scalars/sec (mul -a cu, ecl_hip_mul_batch)", "value": round(n * args.cfg4_steps / dt / 1e6, 2), "unit": "Mscalars/s",
+           "steps": args.cfg4_steps, "ms_per_step": round(dt / args.cfg4_steps * 1e3, 3),
+           "config": {"workload": f"2^{args.cfg4_log2} seeded 256-bit scalars per call from page-locked HOST memory (copies overlapped with the kernels inside the call), "
+                                  "-a cu, 56 MB .blf at density 0.5", "window_bits": wbits, "first_call_ms_incl_table_build": round(t_first * 1e3, 1),
+                      "hits_per_call": int(cnt.value), "pcie_gbs": round(drate * 32 / 1e9, 2),
+                      "oracle_sample": f"the first {nsample} scalars (with {len(planted)} planted) through the oracle's cmd_mul: {len(cpu_lines)} lines, equal",
+                      "found_list_matches_oracle_on_sample": True},
+           "roofline": dict(_roofline_from("mul", "valu_lane_ops_per_scalar", drate, "mul kernels (window sums + hash160 + probe)"),
+                            device_mscalars_s=round(drate / 1e6, 2), ms_per_call_on_stream=round(ms / max(calls, 1), 3))}
+    # (b) the host program: 2^26 lines of 64 hex digits on stdin
+    nl = 1 << args.cfg4_cli_log2
+    b = np.frombuffer(np.random.default_rng(7).bytes(nl * 32), dtype=np.uint8).reshape(nl, 32).copy()
+    for i, k in enumerate(planted):
+        b[17 * i + 5] = np.frombuffer(k.to_bytes(32, "big"), dtype=np.uint8)
+    hexd = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
+    t = np.empty((nl, 65), dtype=np.uint8)
+    t[:, 0:64:2], t[:, 1:64:2], t[:, 64] = hexd[b >> 4], hexd[b & 15], 10
+    src = os.path.join(tmp, "mul_in.txt")
+    t.tofile(src)
+    del t
+    cli = build_host_cli()
+    outp = os.path.join(tmp, "mul_out.txt")
+    best = None
+    for _ in range(2):  # the second run reads the input from the page cache
+        if os.path.exists(outp):
+            os.unlink(outp)
+        t0 = time.perf_counter()
+        pr = subprocess.run([cli, "mul", "-f", blf, "-a", "cu", "-q", "-o", outp], stdin=open(src, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        wall = time.perf_counter() - t0
+        if pr.returncode != 0:
+            raise SystemExit(f"[bench] cfg4: ecloop-hip mul failed: {pr.stderr.decode(errors='replace')[-500:]}")
+        secs, mk, found, checked = _status_of(pr.stderr)
+        if checked != nl:
+            raise SystemExit(f"[bench] cfg4: ecloop-hip mul checked {checked} of {nl} lines")
+        if best is None or mk > best[0]:
+            best = (mk, secs, wall, found)
+    lines = sorted(l.rstrip("\n") for l in open(outp))
+    first = {int.from_bytes(bytes(b[i]), "big") for i in range(nsample)}
+    mine = [l for l in lines if int(l.split("\t")[2], 16) in first]
+    rc, o, no = orc.mul_batch(orc.OrcFilter(bloom_words=words), [int.from_bytes(bytes(b[i]), "big") for i in range(nsample)], a33=True, a65=True)
+    want = sorted(orc.found_lines(o, no))
+    os.unlink(src)
+    if rc != 0 or mine != want or len(want) < 2 * len(planted):
+        raise SystemExit(f"[bench] cfg4: FOUND LIST MISMATCH of the host program on the oracle sample: {len(mine)} lines, oracle {len(want)}")
+    clileg = {"metric": "M lines/sec (ecloop-hip mul -a cu, hex lines on stdin)", "value": best[0], "unit": "Mlines/s", "seconds_by_status_line": best[1],
+              "config": {"workload": f"2^{args.cfg4_cli_log2} lines of 64 hex digits from a file on stdin, -a cu, same filter; rate = the host program's status line, best of 2 runs",
+                         "found": best[3], "wall_s_incl_process_start": round(best[2], 2),
+                         "oracle_sample": f"the first {nsample} lines through the oracle's cmd_mul: {len(want)} lines, equal", "found_list_matches_oracle_on_sample": True}}
+    return {"api": api, "host_program": clileg}
+
+
+def secondary_legs(args, dev_index):
+    out, t_all = {}, time.perf_counter()
+    planted = [0x1000000000000000000000000000000000000000000000000000000000000000 + 0x9E3779B97F4A7C15 * (i + 1) for i in range(16)]
+    t0 = time.perf_counter()
+    out["cfg2"] = leg_cu_endo(args, dev_index)
+    out["cfg2"]["leg_s"] = round(time.perf_counter() - t0, 1)
+    words, blf, tmp = secondary_filter(dev_index, planted)
+    t0 = time.perf_counter()
+    out["cfg3"] = leg_rnd(args, words, blf, tmp)
+    out["cfg3"]["leg_s"] = round(time.perf_counter() - t0, 1)
+    t0 = time.perf_counter()
+    out["cfg4"] = leg_mul(args, dev_index, words, blf, tmp, planted)
+    out["cfg4"]["leg_s"] = round(time.perf_counter() - t0, 1)
+    out["seconds"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -577,6 +889,14 @@ def main():
     ap.add_argument("--mul-log2", type=int, default=24)
     ap.add_argument("--mul-window", type=int, default=22, help="mul: window width of the table (0 = the library's automatic choice)")
     ap.add_argument("--pageable", action="store_true", help="mul: scalars in pageable host memory (staged through pinned buffers by the library)")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1 headline run: skip the `secondary` legs (configs[2], [3], [4])")
+    ap.add_argument("--cfg2-keys-log2", type=int, default=30)
+    ap.add_argument("--cfg2-steps", type=int, default=2)
+    ap.add_argument("--cfg2-filter-n", type=int, default=1_100_000_000, help="entries of the cfg2 filter (1.1e9 = 5.9 GB, configs[2]'s '~6 GB bloom')")
+    ap.add_argument("--cfg3-windows", type=int, default=3)
+    ap.add_argument("--cfg4-log2", type=int, default=24)
+    ap.add_argument("--cfg4-steps", type=int, default=3)
+    ap.add_argument("--cfg4-cli-log2", type=int, default=26)
     args = ap.parse_args()
     t_process = time.perf_counter()
 
@@ -590,14 +910,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     # torch's HIP runtime (its own copy in the wheel) must come up BEFORE libecloop_hip's (/opt/rocm): the other way
     # round torch finds "no ROCm-capable device" - and torch is what fills multi-GB synthetic filters on the device
+    t0 = time.perf_counter()
     import torch
+    SETUP["import_torch_s"] = round(time.perf_counter() - t0, 2)  # 1-2 minutes on a fresh box while the image pages in
+    t0 = time.perf_counter()
     if torch.cuda.is_available():
         torch.cuda.init()
         if local < torch.cuda.device_count():  # otherwise: refused below (or folded onto the GPUs that exist by the test hook)
             torch.cuda.set_device(local)
+    SETUP["torch_cuda_init_s"] = round(time.perf_counter() - t0, 2)
+    t0 = time.perf_counter()
     if local == 0:
-        from ecloop_amd.build import build_library
+        from ecloop_amd.build import build_library, library_is_current
+        SETUP["library_was_current"] = library_is_current()  # decided by the source hash stamped beside the .so, not by file times
         build_library()  # no-op when the in-tree .so is current (it travels with the snapshot); builds it if it is missing
+    SETUP["library_build_check_s"] = round(time.perf_counter() - t0, 2)
     # test hook (not used by the driver): ECL_BENCH_SHARE_GPU=1 lets several workers run on the GPUs that exist
     # (worker g on device g mod count), to exercise the N>1 code path on a single-GPU box
     share = os.environ.get("ECL_BENCH_SHARE_GPU") == "1"
