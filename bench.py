@@ -661,28 +661,30 @@ def leg_cu_endo(args, dev_index):
                              kernel_mkeys_s=round(krate / 1e6, 2))}
 
 
-def secondary_filter(dev_index, scalars_to_plant):
-    """the 56 MB filter of the cfg3 / cfg4 legs: random words at density 0.5 (~4100 false positives per 2^32 hash160: enough
-    lines for an oracle sample to mean something) + the hash160s of the given scalars' public keys; -> (words, path of the .blf)"""
+def secondary_filter(dev_index, scalars_to_plant, mode="a&(b|c)", name="secondary"):
+    """a 56 MB filter for the cfg3 / cfg4 legs: random words at the .blf design density 0.375 (mode "a&(b|c)"; the timed runs) or
+    at density 0.5 (mode "a": ~4100 false positives per 2^32 hash160, so that an oracle sample has lines to compare; the check
+    run of cfg3) + the hash160s of the given scalars' public keys; -> (words, path of the .blf, its directory)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from synth import synth_bloom_words, write_blf
     from ecloop_amd.capi import Device
-    words = synth_bloom_words(7000003, 41, "a")
+    words = synth_bloom_words(7000003, 41, mode)
     d = Device(dev_index, a33=True, a65=True)
     try:
-        d.set_bloom(words)
-        xs, ys, _ = d.diag_mulg(scalars_to_plant)
-        h33, h65 = d.diag_hash160(xs, ys)
-        d.bloom_insert(h33)
-        d.bloom_insert(h65)
-        words = d.get_bloom(len(words))
+        if scalars_to_plant:
+            d.set_bloom(words)
+            xs, ys, _ = d.diag_mulg(scalars_to_plant)
+            h33, h65 = d.diag_hash160(xs, ys)
+            d.bloom_insert(h33)
+            d.bloom_insert(h65)
+            words = d.get_bloom(len(words))
     finally:
         d.close()
     tmp = tempfile.mkdtemp(prefix="eclbench2")
     import atexit
     import shutil
     atexit.register(shutil.rmtree, tmp, ignore_errors=True)
-    path = os.path.join(tmp, "secondary.blf")
+    path = os.path.join(tmp, name + ".blf")
     write_blf(path, words)
     return words, path, tmp
 
@@ -695,51 +697,53 @@ def _status_of(stderr_bytes):
     return float(m.group(1)), float(m.group(2)), int(m.group(3).replace(",", "")), int(m.group(4).replace(",", ""))
 
 
-def leg_rnd(args, words, blf, tmp):
-    """configs[3] on one GPU: `ecloop-hip rnd -d 128:32` - random 2^32-key windows at stride 2^128, a new base point per window"""
+def leg_rnd(args, blf, dense_words, dense_blf, tmp):
+    """configs[3] on one GPU: `ecloop-hip rnd -d 128:32` - random 2^32-key windows at stride 2^128, a new base point per window.
+    Timed on the design-density filter (a window's handful of false positives says little); the same command line is then run for
+    one window on a filter of density 0.5, whose found list over a slice of the printed window is compared with the oracle's."""
     from ecloop_amd.build import build_host_cli
     orc = _orc()
     cli = build_host_cli()
     lo, hi = (1 << 167) + 0x1234567, (1 << 168) - 0x7654321
-    out = os.path.join(tmp, "rnd.txt")
+
+    def rnd(filter_path, nwin, out):
+        env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS=str(nwin), ECLOOP_HIP_STATS="1")
+        t0 = time.perf_counter()
+        pr = subprocess.run([cli, "rnd", "-f", filter_path, "-r", f"{lo:x}:{hi:x}", "-d", "128:32", "-seed", "bench", "-t", "1", "-q", "-o", out],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        wall = time.perf_counter() - t0
+        if pr.returncode != 0:
+            raise SystemExit(f"[bench] cfg3: ecloop-hip rnd failed: {pr.stderr.decode(errors='replace')[-500:]}")
+        text = pr.stdout.decode(errors="replace")
+        secs, mkeys, found, checked = _status_of(pr.stderr)
+        masks = [int(l.replace(" ", ""), 16) for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
+        m = re.search(r"gpu 0: (\d+) launches, ([\d.]+) ms in the search kernel, (\d+) set-ups, ([\d.]+) ms in set-up kernels", text)
+        if len(masks) != 2 * nwin or checked != nwin << 32 or not m:
+            raise SystemExit(f"[bench] cfg3: unexpected output of ecloop-hip rnd ({len(masks)} masks, {checked} checked)")
+        lines = sorted(l.rstrip("\n") for l in open(out)) if os.path.exists(out) else []
+        return secs, mkeys, found, checked, masks, float(m.group(2)), float(m.group(4)), wall, lines
+
     nwin = args.cfg3_windows
-    env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS=str(nwin), ECLOOP_HIP_STATS="1")
+    secs, mkeys, found, checked, masks, kernel_ms, setup_ms, wall, _ = rnd(blf, nwin, os.path.join(tmp, "rnd.txt"))
+    # the check run: one window, dense filter, the oracle over the first 2^24 keys of the printed window (stride 2^128, full-size jobs)
     t0 = time.perf_counter()
-    pr = subprocess.run([cli, "rnd", "-f", blf, "-r", f"{lo:x}:{hi:x}", "-d", "128:32", "-seed", "bench", "-t", "1", "-q", "-o", out],
-                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
-    wall = time.perf_counter() - t0
-    if pr.returncode != 0:
-        raise SystemExit(f"[bench] cfg3: ecloop-hip rnd failed: {pr.stderr.decode(errors='replace')[-500:]}")
-    text = pr.stdout.decode(errors="replace")
-    secs, mkeys, found, checked = _status_of(pr.stderr)
-    masks = [int(l.replace(" ", ""), 16) for l in text.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
-    m = re.search(r"gpu 0: (\d+) launches, ([\d.]+) ms in the search kernel, (\d+) set-ups, ([\d.]+) ms in set-up kernels", text)
-    if len(masks) != 2 * nwin or checked != nwin << 32 or not m:
-        raise SystemExit(f"[bench] cfg3: unexpected output of ecloop-hip rnd ({len(masks)} masks, {checked} checked)")
-    kernel_ms, setup_ms = float(m.group(2)), float(m.group(4))
-    lines = sorted(l.rstrip("\n") for l in open(out))
-    # the oracle over a prefix of every printed window: 2^24 keys at stride 2^128 with cmd_rnd's full-size jobs
-    t0 = time.perf_counter()
-    flt = orc.OrcFilter(bloom_words=words)
-    threads, part, compared = min(os.cpu_count() or 1, 64), 1 << 24, 0
-    for w in range(nwin):
-        s = masks[2 * w]
-        rc, o, n, _, hashed = orc.add_range(flt, s, s + ((part - 1) << 128), offs=128, rnd=True, verify=False, threads=threads, cap=1 << 16)
-        want = sorted(orc.found_lines(o, n))
-        mine = [l for l in lines if (int(l.split("\t")[2], 16) - s) % (1 << 128) == 0 and 0 <= (int(l.split("\t")[2], 16) - s) >> 128 < part]
-        if rc != 0 or hashed != part or mine != want:
-            raise SystemExit(f"[bench] cfg3: FOUND LIST MISMATCH on the oracle sample of window {w}: gpu {len(mine)} lines, oracle {len(want)}")
-        compared += len(want)
+    _, _, _, _, cmasks, _, _, _, lines = rnd(dense_blf, 1, os.path.join(tmp, "rnd_check.txt"))
+    threads, part, s0 = min(os.cpu_count() or 1, 64), 1 << 24, cmasks[0]
+    rc, o, n, _, hashed = orc.add_range(orc.OrcFilter(bloom_words=dense_words), s0, s0 + ((part - 1) << 128), offs=128, rnd=True, verify=False,
+                                        threads=threads, cap=1 << 16)
+    want = sorted(orc.found_lines(o, n))
+    mine = [l for l in lines if (int(l.split("\t")[2], 16) - s0) % (1 << 128) == 0 and 0 <= (int(l.split("\t")[2], 16) - s0) >> 128 < part]
     t_check = time.perf_counter() - t0
-    if compared < 8:
-        raise SystemExit(f"[bench] cfg3: the oracle sample holds only {compared} lines: the check means nothing")
+    if rc != 0 or hashed != part or mine != want or len(want) < 8:
+        raise SystemExit(f"[bench] cfg3: FOUND LIST MISMATCH on the oracle sample: gpu {len(mine)} lines, oracle {len(want)} (rc {rc})")
     return {"metric": "Mkeys/sec (rnd -d 128:32)", "value": mkeys, "unit": "Mkeys/s", "windows": nwin, "seconds_by_status_line": secs,
-            "config": {"workload": f"ecloop-hip rnd -d 128:32 -t 1: {nwin} random windows of 2^32 keys at stride 2^128 on a 168-bit range, 56 MB .blf at density 0.5; "
-                                   "rate = the host program's own status line (set-up of every window included, process start-up not)",
+            "config": {"workload": f"ecloop-hip rnd -d 128:32 -t 1: {nwin} random windows of 2^32 keys at stride 2^128 on a 168-bit range, 56 MB .blf at the design "
+                                   "density; rate = the host program's own status line (set-up of every window included, process start-up not)",
                        "found": found, "checked": checked, "wall_s_incl_process_start": round(wall, 2),
                        "device_ms_search_kernel": kernel_ms, "device_ms_window_setup": setup_ms, "setup_share": round(setup_ms / (kernel_ms + setup_ms), 5),
                        "kernel_mkeys_s": round(checked / (kernel_ms * 1e-3) / 1e6, 2),
-                       "oracle_sample": f"first 2^24 keys of each of the {nwin} printed windows on {threads} host threads: {compared} lines, equal",
+                       "oracle_sample": f"same command, one window, filter of density 0.5: first 2^24 keys of the printed window on {threads} host threads: "
+                                        f"{len(want)} lines, equal",
                        "found_list_matches_oracle_on_sample": True, "check_s": round(t_check, 1)}}
 
 
@@ -799,7 +803,7 @@ def leg_mul(args, dev_index, words, blf, tmp, planted):
     api = {"metric": "M scalars/sec (mul -a cu, ecl_hip_mul_batch)", "value": round(n * args.cfg4_steps / dt / 1e6, 2), "unit": "Mscalars/s",
            "steps": args.cfg4_steps, "ms_per_step": round(dt / args.cfg4_steps * 1e3, 3),
            "config": {"workload": f"2^{args.cfg4_log2} seeded 256-bit scalars per call from page-locked HOST memory (copies overlapped with the kernels inside the call), "
-                                  "-a cu, 56 MB .blf at density 0.5", "window_bits": wbits, "first_call_ms_incl_table_build": round(t_first * 1e3, 1),
+                                  "-a cu, 56 MB .blf at the design density", "window_bits": wbits, "first_call_ms_incl_table_build": round(t_first * 1e3, 1),
                       "hits_per_call": int(cnt.value), "pcie_gbs": round(drate * 32 / 1e9, 2),
                       "oracle_sample": f"the first {nsample} scalars (with {len(planted)} planted) through the oracle's cmd_mul: {len(cpu_lines)} lines, equal",
                       "found_list_matches_oracle_on_sample": True},
@@ -854,8 +858,9 @@ def secondary_legs(args, dev_index):
     out["cfg2"] = leg_cu_endo(args, dev_index)
     out["cfg2"]["leg_s"] = round(time.perf_counter() - t0, 1)
     words, blf, tmp = secondary_filter(dev_index, planted)
+    dense_words, dense_blf, _ = secondary_filter(dev_index, [], mode="a", name="dense")
     t0 = time.perf_counter()
-    out["cfg3"] = leg_rnd(args, words, blf, tmp)
+    out["cfg3"] = leg_rnd(args, blf, dense_words, dense_blf, tmp)
     out["cfg3"]["leg_s"] = round(time.perf_counter() - t0, 1)
     t0 = time.perf_counter()
     out["cfg4"] = leg_mul(args, dev_index, words, blf, tmp, planted)

@@ -218,6 +218,46 @@ __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
 #endif
   return acc;
 }
+#ifndef ECL_MUL_MMADD
+#define ECL_MUL_MMADD 1  /* A/B: 0 = the second point goes through the general mixed addition too (one code body less) */
+#endif
+// the complete sum out of line: the fallback of a scalar whose lazy sum ended with Z = 0 (never taken by a random scalar)
+__device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { return wtab_sum(kk, t); }
+// The same sum for k_mul_check's hot loop: lazy additions without exceptional cases (ec.h: jac_madd_lazy; the caller tests Z once
+// at the end), the second point of a sum added to the first as affine + affine (4M + 2S instead of 8M + 3S).  State: npts = 0
+// nothing yet, 1 = one table point held as it is (acc.X, acc.Y), >= 2 = Jacobian.  Returns with acc.inf = 1 for an all-zero scalar
+// and acc.Z = 1 for a single point.
+__device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+  u32 npts = 0;
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  u32 dnext = wtab_digit(kk, t, 0);
+  if (dnext) {
+    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = dnext;
+    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    if (dnext) {
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+    }
+    if (!digit) continue;
+    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
+    if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
+#if ECL_MUL_MMADD
+    else if (npts == 1) acc = jac_mmadd_lazy(acc.X, acc.Y, qx, qy);
+#endif
+    else acc = jac_madd_lazy(acc, qx, qy);
+    ++npts;
+  }
+  return acc;
+}
 // rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
 // consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
 __global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
@@ -286,7 +326,7 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
-#define MUL_R 16u  /* at most; short batches take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
+#define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
@@ -301,7 +341,10 @@ __global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u3
     u32 kk[9];
     const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
     kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
-    const jac acc = wtab_sum(kk, gtab);
+    jac acc = wtab_sum_lazy(kk, gtab);
+    // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves Z = 0, and a zero in
+    // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
+    if (!acc.inf && __builtin_expect(fe_is_zero(acc.Z), 0)) acc = wtab_sum_complete(kk, gtab);
     const fe z = acc.inf ? fe_one() : acc.Z;
     infmask |= (acc.inf ? 1u : 0u) << r;
     u32* p = tmp + (size_t)r * 36 * nt + t;
@@ -1215,7 +1258,7 @@ static int ensure_gtable(ecl_hip* h) {
 // out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
 // are compared with the double-and-add kernel.
 #define MUL_W_MIN 8u
-#define MUL_W_MAX 24u
+#define MUL_W_MAX 26u  /* 10 rows x 2^26 points: 43 GB */
 #define MUL_W_START 20u               /* 13 rows x 2^20 points, 872 MB: first call 48 ms against 41 ms at 14 bits and 47 at 18 */
 #define MUL_W_LONG 22u                /* 12 rows x 2^22 points, 3.0 GB: ~50 ms */
 #define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: at 955 vs 1006 M scalars/s the
@@ -1223,15 +1266,20 @@ static int ensure_gtable(ecl_hip* h) {
 struct multab_t {
   u32* d = nullptr;
   int refs = 0;
+  std::mutex mu;  // held while the table is built: a context that wants the same table waits for it, one that wants another width does not
 };
-static std::mutex g_multab_mu;
+static std::mutex g_multab_mu;  // guards the map only (its nodes stay where they are)
 static std::map<std::pair<int, u32>, multab_t> g_multab;
+static multab_t* multab_entry(int dev, u32 W) {
+  std::lock_guard<std::mutex> lk(g_multab_mu);
+  return &g_multab[{dev, W}];
+}
 
 static void release_multable(ecl_hip* h) {
   if (!h->d_multab) return;
-  std::lock_guard<std::mutex> lk(g_multab_mu);
-  multab_t& t = g_multab[{h->dev, h->multab_W}];
-  if (--t.refs == 0) (void)hipFree(t.d), t.d = nullptr;
+  multab_t* t = multab_entry(h->dev, h->multab_W);
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (--t->refs == 0) (void)hipFree(t->d), t->d = nullptr;
   h->d_multab = nullptr, h->multab_W = 0;
 }
 
@@ -1299,20 +1347,24 @@ static int build_multable(ecl_hip* h, u32 W, u32** out) {
   return ECL_OK;
 }
 
-// the table of width W for this context (drops the one it held if that was another width)
+// the table of width W for this context.  The new table is acquired (built if nobody has it yet) BEFORE the one the context holds is
+// given back: a failed switch - no room for the wider table - leaves the context with the table it had, nothing to rebuild.
 static int ensure_multable(ecl_hip* h, u32 W) {
   if (h->d_multab && h->multab_W == W) return ECL_OK;
+  multab_t* t = multab_entry(h->dev, W);
+  {
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (!t->d) {
+      const int rc = build_multable(h, W, &t->d);
+      if (rc != ECL_OK) return rc;
+    }
+    ++t->refs;
+  }
   if (h->d_multab) {
     HIPCHK(h, hipStreamSynchronize(h->stream));  // kernels of earlier calls may still read the old table
     release_multable(h);
   }
-  std::lock_guard<std::mutex> lk(g_multab_mu);
-  multab_t& t = g_multab[{h->dev, W}];
-  if (!t.d) {
-    const int rc = build_multable(h, W, &t.d);
-    if (rc != ECL_OK) return rc;
-  }
-  ++t.refs, h->d_multab = t.d, h->multab_W = W;
+  h->d_multab = t->d, h->multab_W = W;
   return ECL_OK;
 }
 
@@ -1365,13 +1417,27 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
 static u32 mul_window_for(const ecl_hip* h, u32 n) {
   return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER && !h->mul_long_failed ? MUL_W_LONG : MUL_W_START);
 }
+// mul_setup at the width in force; if the automatic choice was the long table and there is no room for it (3.6 GB while it is
+// built), the context stays on the short one for good.  Shared by ecl_hip_mul_batch, ecl_hip_mul_batch_raw and ecl_hip_reserve_mul.
+static int mul_setup_auto(ecl_hip* h, u32 n, u32* W_used) {
+  u32 W = mul_window_for(h, n);
+  int rc = mul_setup(h, n, W);
+  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {
+    (void)hipGetLastError();
+    h->mul_long_failed = true, W = MUL_W_START;
+    rc = mul_setup(h, n, W);
+  }
+  *W_used = W;
+  return rc;
+}
 
 extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
   if (!h || n == 0) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = ensure_found(h, raw_cap_of(h, cap ? cap : 1) + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  return mul_setup(h, n, mul_window_for(h, n));
+  u32 W;
+  return mul_setup_auto(h, n, &W);
 }
 
 extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
@@ -1384,14 +1450,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  u32 W = mul_window_for(h, n);
-  rc = mul_setup(h, n, W);
-  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {  // no room for the long table (3.6 GB while it is built): stay on the short one
-    (void)hipGetLastError();
-    h->mul_long_failed = true, W = MUL_W_START;
-    rc = mul_setup(h, n, W);
-  }
-  if (rc != ECL_OK) return rc;
+  u32 W;
+  if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
   h->mul_seen += n;
   // Scalars in page-locked host memory (ecl_hip_alloc_host / ecl_hip_pin_host) go to the device by DMA straight from the
@@ -1420,20 +1480,21 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
-  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum over 19 x 14 bits is k*G for any
+  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel: 2^20 scalars, 2^21 for calls of
-  // 2^25 and more, and the first piece a quarter of the others - nothing overlaps its copy.  Measured, M scalars/s by call
-  // size 2^22 / 2^24 / 2^26 (profiles/r03_mul_pieces.txt): 22-bit table, pieces of 2^20: 848 / 970 / 994, 2^21: 803 / 947 /
-  // 1034, 2^22 (one piece per call up to 2^22: 2.6 ms of copy and then the kernel): 622 / 894 / 1006; 18-bit table:
-  // 768 / 850 / 870, 729 / 869 / 908, 565 / 813 / 896.  Fewer than 2^17 threads per kernel cost more than they save
-  // (pieces of 2^19 with 8 scalars per thread: 735 / 776 / 782 on 18 bits).
-  u32 chunk = h->kbuf_cap;
-  const u32 piece = n >= (1u << 25) ? 1u << 21 : 1u << 20;
-  if (piece < chunk) chunk = piece;
+  // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel.  Round 3 used pieces of 2^20 scalars
+  // (profiles/r03_mul_pieces.txt: 848 / 970 / 994 M scalars/s on calls of 2^22 / 2^24 / 2^26; 2^22-scalar pieces 622 / 894 / 1006);
+  // fewer than 2^17 threads per kernel cost more than they save.  Now the
+  // pieces grow: 2^18, 2^19, ... up to the staging size (2^22): the first copy is short, and the later pieces give a thread up to
+  // 32 scalars to share its inversion (270 multiplications: 34 per scalar at 8 scalars per thread, 8 at 32)
+  static const u32 first_log2 = getenv("ECL_HIP_MUL_FIRST") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST")) : 18u;   // tuning hooks (A/B runs)
+  static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 200u;
+  static const u32 top_log2 = getenv("ECL_HIP_MUL_TOP") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP")) : 22u;
+  const u32 top = h->kbuf_cap < (1u << top_log2) ? h->kbuf_cap : 1u << top_log2;
+  u32 lim = top < (1u << first_log2) ? top : 1u << first_log2;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c) {
-    const u32 b = c & 1, lim = c == 0 && n > chunk ? chunk / 4 : chunk;
+  for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
+    const u32 b = c & 1;
     m = n - at < lim ? n - at : lim;
     if (c >= 2) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel two chunks back is done with this pair
     const void* src = scalars[at];
@@ -1443,7 +1504,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
     // scalars per thread: as many as keep >= 2^17 threads in flight (two waves per SIMD hide the table gathers; the host
     // program keeps two contexts per GPU busy, which fills the other half), at most MUL_R
-    u32 R = m >> 17;
+    static const u32 nt_target = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 1u << 17;  // tuning hook (A/B runs)
+    u32 R = m / nt_target;
     R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
     const u32 nt = (m + R - 1) / R;
     dim3 grid((nt + 255) / 256), blk(256);
@@ -1478,14 +1540,8 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
-  u32 W = mul_window_for(h, n);
-  rc = mul_setup(h, n, W);
-  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {
-    (void)hipGetLastError();
-    h->mul_long_failed = true, W = MUL_W_START;
-    rc = mul_setup(h, n, W);
-  }
-  if (rc != ECL_OK) return rc;
+  u32 W;
+  if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
   h->mul_seen += n;
   const size_t text_words = ((size_t)text_bytes + 3) / 4 + 2;  // two spare words: the gather reads one word past the last byte

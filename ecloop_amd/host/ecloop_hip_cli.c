@@ -513,8 +513,10 @@ typedef struct {
   sc hashed;         /* keys to hash (256-bit: `add` without -r walks ~2^256 / stride keys) */
   sc next;           /* keys handed out so far */
   u64 chunk;         /* keys per hand-out = per device call */
+  bool fixed;        /* one contiguous shard per device thread (chunk g belongs to thread g) instead of the shared counter */
   u64 status_total;  /* what the status counter must have gained at the end (0: not representable, add as we go) */
   u64 status_given;
+  int shards_left;   /* fixed shards not yet taken */
   u64 mult;          /* status units per key when status_total is 0 */
   pthread_mutex_t mu;
 } scan_t;
@@ -537,18 +539,24 @@ static void *scan_worker(void *arg) {
   run_t *run = sn->run;
   u32 cap = 4096;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
-  for (;;) {
+  for (bool first = true;; first = false) {
     pthread_mutex_lock(&sn->mu);
     sc lo = sn->next, left;
-    if (sc_cmp(&lo, &sn->hashed) >= 0) { pthread_mutex_unlock(&sn->mu); break; }
+    if (sn->fixed) { /* thread g's own shard: keys [g * chunk, (g + 1) * chunk) of the scan, one device call */
+      lo = sc_u64(sn->chunk * (u64)w->g);
+      if (!first || sc_cmp(&lo, &sn->hashed) >= 0) { pthread_mutex_unlock(&sn->mu); break; }
+    } else if (sc_cmp(&lo, &sn->hashed) >= 0) { pthread_mutex_unlock(&sn->mu); break; }
     sc_subraw(&left, &sn->hashed, &lo);
     u64 n = (left.w[1] | left.w[2] | left.w[3]) || left.w[0] > sn->chunk ? sn->chunk : left.w[0];
-    sn->next = sc_add_u64_raw(lo, n);
-    bool last = sc_cmp(&sn->next, &sn->hashed) >= 0;
+    sc upto_key = sc_add_u64_raw(lo, n);
+    if (sn->fixed) sn->shards_left--;
+    else sn->next = upto_key;
+    bool last = sn->fixed ? sn->shards_left == 0 : sc_cmp(&sn->next, &sn->hashed) >= 0;
     /* status counter: the reference adds job_size (x6 with endo) per job (main.c:431); spread over the chunks */
     u64 st;
     if (!sn->status_total) st = n * sn->mult;
     else if (last) st = sn->status_total - sn->status_given;
+    else if (sn->fixed) st = (u64)((u128)sn->status_total * n / sn->hashed.w[0]); /* this shard's share; the last one rounds up */
     else {
       u128 done = (u128)sn->next.w[0]; /* status_total != 0 implies hashed < 2^63 */
       u64 upto = (u64)((u128)sn->status_total * done / sn->hashed.w[0]);
@@ -583,11 +591,20 @@ static void *scan_worker(void *arg) {
 }
 
 /* keys per hand-out.  One GPU: whole sweeps of the walk (2^32 keys at the default geometry), which continue on the
-   device without re-initialisation.  Several GPUs: at least two chunks per GPU so that uneven clocks even out, at
-   least 2^27 keys (10 ms of kernel against ~0.4 ms of per-call set-up), at most 2^30. */
-static u64 scan_chunk(const run_t *run, const sc *hashed) {
+   device without re-initialisation.  Several GPUs, a scan of at most 2^33 keys (one 2^32-key range - the configuration the
+   headline metric is quoted on -, a `rnd` window): ONE contiguous shard per GPU, a single device call each (*fixed) - a call of
+   2^29 keys runs 2 % below a 2^30-key one and every call pays its re-positioning, so halving the shards to even out clocks that
+   differ by a percent or two loses more than it wins.  Longer scans: the shared counter, at least two chunks per GPU so that uneven
+   clocks even out, at least 2^27 keys (10 ms of kernel against ~0.4 ms of per-call set-up), at most 2^30. */
+static u64 scan_chunk(const run_t *run, const sc *hashed, bool *fixed) {
+  *fixed = false;
   if (run->ngpus <= 1) return LAUNCH_KEYS;
   if (hashed->w[1] | hashed->w[2] | hashed->w[3]) return 1ull << 30;
+  if (hashed->w[0] <= (1ull << 33) && !getenv("ECLOOP_HIP_SHARED_COUNTER")) {
+    u64 c = (hashed->w[0] + (u64)run->ngpus - 1) / (u64)run->ngpus;
+    *fixed = true;
+    return (c + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
+  }
   u64 c = (hashed->w[0] + 2 * (u64)run->ngpus - 1) / (2 * (u64)run->ngpus);
   c = (c + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
   if (c < (1ull << 27)) c = 1ull << 27;
@@ -642,7 +659,9 @@ static void scan_plan(run_t *run, sc rs, sc re, bool full_jobs, scan_t *sn) {
     for (int i = 0; i < 21; ++i) sc_addraw(&h, &h, &h); /* njobs < 2^235 here: no wrap */
     sn->hashed = h;
   }
-  sn->chunk = scan_chunk(run, &sn->hashed);
+  sn->chunk = scan_chunk(run, &sn->hashed, &sn->fixed);
+  if (sn->fixed) /* shards that hold keys: a scan shorter than ngpus * 2048 keys leaves the last threads without one */
+    sn->shards_left = (int)((sn->hashed.w[0] + sn->chunk - 1) / sn->chunk);
 }
 
 /* one scan, spread over the GPUs */
@@ -660,9 +679,25 @@ static void scan_range(run_t *run, sc rs, sc re, bool full_jobs) {
   pthread_mutex_destroy(&sn.mu);
 }
 
+/* ECLOOP_HIP_STATS: where each device context's time went - calls of the search kernel, and what the non-contiguous ones paid
+   for re-positioning the walk */
+static void print_device_stats(run_t *run) {
+  if (!getenv("ECLOOP_HIP_STATS")) return;
+  for (int g = 0; g < run->ngpus; ++g) {
+    double kernel_ms = 0, setup_ms = 0;
+    u64 launches = 0, keys = 0, setups = 0;
+    ecl_hip_get_timing(run->dev[g], &kernel_ms, &launches, &keys);
+    ecl_hip_get_setup_timing(run->dev[g], &setup_ms, &setups);
+    printf("gpu %d: %llu launches, %.3f ms in the search kernel, %llu set-ups, %.3f ms in set-up kernels (%.2f %%)\n", g,
+           (unsigned long long)launches, kernel_ms, (unsigned long long)setups, setup_ms,
+           kernel_ms > 0 ? 100.0 * setup_ms / (kernel_ms + setup_ms) : 0.0);
+  }
+}
+
 static void cmd_add(run_t *run) {
   report_restart_clock(&run->rep);
   scan_range(run, run->range_s, run->range_e, false);
+  print_device_stats(run);
   report_close(&run->rep);
 }
 
@@ -1421,16 +1456,7 @@ static void cmd_rnd(run_t *run) {
     const bool whole_range = !sc_cmp(&w.first, &A) && !sc_cmp(&w.last, &B);
     if (whole_range || (limit && ++done >= limit)) break;
   }
-  if (getenv("ECLOOP_HIP_STATS")) /* where the device time of the windows went: search kernel vs per-window set-up */
-    for (int g = 0; g < run->ngpus; ++g) {
-      double kernel_ms = 0, setup_ms = 0;
-      u64 launches = 0, keys = 0, setups = 0;
-      ecl_hip_get_timing(run->dev[g], &kernel_ms, &launches, &keys);
-      ecl_hip_get_setup_timing(run->dev[g], &setup_ms, &setups);
-      printf("gpu %d: %llu launches, %.3f ms in the search kernel, %llu set-ups, %.3f ms in set-up kernels (%.2f %%)\n", g,
-             (unsigned long long)launches, kernel_ms, (unsigned long long)setups, setup_ms,
-             kernel_ms > 0 ? 100.0 * setup_ms / (kernel_ms + setup_ms) : 0.0);
-    }
+  print_device_stats(run);
   report_close(rep);
 }
 
@@ -1826,7 +1852,8 @@ static double bring_up(run_t *run, int shown, int real) {
       for (u32 i = 0; i < run->ord_offs && i < 256; ++i) keys = sc_shr1(keys);
       keys = sc_add_u64_raw(keys, 4096);
     }
-    largest_call = scan_chunk(run, &keys);
+    bool fixed_shards;
+    largest_call = scan_chunk(run, &keys, &fixed_shards);
     if (!(keys.w[1] | keys.w[2] | keys.w[3]) && keys.w[0] < largest_call) largest_call = keys.w[0];
   }
   const u32 flags = (run->a33 ? ECL_ADDR33 : 0) | (run->a65 ? ECL_ADDR65 : 0) | (run->endo ? ECL_ENDO : 0);

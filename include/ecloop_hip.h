@@ -150,7 +150,7 @@ int ecl_hip_mul_batch_raw(ecl_hip *h, const uint8_t *text, uint32_t text_bytes, 
    counterpart of ecl_hip_reserve for `mul`; the reference builds its table at the start of cmd_mul (main.c:543). */
 int ecl_hip_reserve_mul(ecl_hip *h, uint32_t n, uint32_t cap);
 
-/* Optional: fix the window width of this context's `mul` table (8..24 bits; 0 = automatic, the default) from the next
+/* Optional: fix the window width of this context's `mul` table (8..26 bits; 0 = automatic, the default) from the next
    ecl_hip_mul_batch on - a caller that knows it will multiply billions of scalars takes 22 at once.  No reference
    counterpart other than the compile-time _GTABLE_W (lib/ecc.c:876). */
 int ecl_hip_set_mul_window(ecl_hip *h, uint32_t bits);

@@ -96,23 +96,32 @@ def test_add_known_answers(cli, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ngpu", [2, 3, 8])
-def test_add_sharded_over_device_threads(cli, tmp_path, ngpu):
-    """`-t N` = N device threads, the range cut into N contiguous shards.  On a one-GPU box the test hook
+@pytest.mark.parametrize("ngpu,counter", [(2, False), (3, False), (8, False), (3, True)])
+def test_add_sharded_over_device_threads(cli, tmp_path, ngpu, counter):
+    """`-t N` = N device threads.  A scan of at most 2^33 keys is cut into N contiguous shards, ONE device call per
+    thread (the per-context `launches` of ECLOOP_HIP_STATS); longer scans - here forced with ECLOOP_HIP_SHARED_COUNTER - pull
+    chunks from the shared counter like the reference's workers pull jobs (main.c:418-431).  On a one-GPU box the test hook
     ECLOOP_HIP_SHARE_GPU lets the N threads share the device: found lists and status counters must not depend on N."""
-    env = dict(os.environ, ECLOOP_HIP_SHARE_GPU=str(ngpu))
+    env = dict(os.environ, ECLOOP_HIP_SHARE_GPU=str(ngpu), ECLOOP_HIP_STATS="1")
+    if counter:
+        env["ECLOOP_HIP_SHARED_COUNTER"] = "1"
     puz = os.path.join(GOLD, "btc-puzzles-hash")
     ones = str(tmp_path / "ones.blf")
     write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
-    for name, args in [("make_add_8000_ffffff", ["-f", puz, "-r", "8000:ffffff"]),
-                       ("endo_cu_list_8000_fffff", ["-f", puz, "-r", "8000:fffff", "-a", "cu", "-endo"]),
-                       ("dump33_overrun_9000_9801", ["-f", ones, "-r", "9000:9801"]),
-                       ("dump_cu_endo_8000_87ff", ["-f", ones, "-r", "8000:87ff", "-a", "cu", "-endo"])]:
+    for name, args, hashed in [("make_add_8000_ffffff", ["-f", puz, "-r", "8000:ffffff"], 1 << 24),
+                               ("endo_cu_list_8000_fffff", ["-f", puz, "-r", "8000:fffff", "-a", "cu", "-endo"], 1015808),
+                               ("dump33_overrun_9000_9801", ["-f", ones, "-r", "9000:9801"], 4096),
+                               ("dump_cu_endo_8000_87ff", ["-f", ones, "-r", "8000:87ff", "-a", "cu", "-endo"], 2048)]:
         lines, status, stdout = run(cli, ["add", "-t", str(ngpu)] + args, out=str(tmp_path / (name + ".txt")), env=env)
         g = G[name]
         assert "gpus: %d " % ngpu in stdout
         assert len(lines) == g.get("count", len(g.get("lines", []))) and digest(lines) == g["sha256_sorted"], name
         assert counts(status) == (g["status_found"], g["status_checked"]), name
+        calls = [int(m) for m in re.findall(r"^gpu \d+: (\d+) launches", stdout, re.M)]
+        assert len(calls) == ngpu and sum(calls) >= 1
+        if not counter:  # static shards: whole 2048-key groups, ceil(hashed / N) per thread, one call each
+            per = -(-(-(-hashed // ngpu)) // 2048) * 2048
+            assert sorted(calls, reverse=True) == [1] * -(-hashed // per) + [0] * (ngpu - -(-hashed // per)), (name, calls)
 
 
 @pytest.mark.gpu

@@ -257,10 +257,10 @@ def test_mult_verify_gtable_against_double_and_add():
         d.close()
 
 
-@pytest.mark.parametrize("n", [(1 << 18) + 77, (1 << 20) + 4099, (1 << 22) + (1 << 19) + 5])
+@pytest.mark.parametrize("n", [(1 << 18) + 77, (1 << 20) + 4099, (1 << 22) + (1 << 19) + 5, (1 << 23) + 12345])
 def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
-    """ecl_hip_mul_batch at sizes that select 1, 4 and 16 + 2 scalars per thread (one shared inversion per thread,
-    lib/ecc.c:695-707) and more than one staged chunk: with the all-ones filter every scalar comes back once, and every
+    """ecl_hip_mul_batch at sizes whose pieces (2^18, 2^19, ... 2^22 scalars, then the rest) give a thread 2, 4, 8, 16 and - the
+    largest size - 32 scalars (one shared inversion per thread, lib/ecc.c:695-707), over several staged pieces: with the all-ones filter every scalar comes back once, and every
     hash160 must equal the one the double-and-add kernel + hash kernel give for the same scalar; scalars that are
     0 (mod n) inside a batch are skipped without disturbing their neighbours' shared inversion."""
     import ctypes as C
@@ -334,7 +334,7 @@ def _digit_edge_scalars(rng, n, W):
     return K
 
 
-@pytest.mark.parametrize("W", [8, 13, 14, 16, 18, 20, 22, 24])
+@pytest.mark.parametrize("W", [8, 13, 14, 16, 18, 20, 22, 24, 26])
 def test_mul_every_window_width_against_double_and_add(W):
     """the window width of `mul`'s table is a run-time choice (ecl_hip_set_mul_window; the reference's is the compile-time
     _GTABLE_W = 14, lib/ecc.c:876): results must not depend on it.  Widths that divide 256 and widths that leave a
@@ -348,7 +348,7 @@ def test_mul_every_window_width_against_double_and_add(W):
         d.set_mul_window(W)
         assert _mul_all_against_double_and_add(d, K) == n and d.mul_window() == W
         with pytest.raises(Exception):
-            d.set_mul_window(25)
+            d.set_mul_window(27)
         with pytest.raises(Exception):
             d.set_mul_window(7)
     finally:

@@ -7,7 +7,7 @@ FILTERS=${1:-10000000}; shift
 for lib in shipped "$@"; do
   path=$PWD/$lib; [ "$lib" = shipped ] && path=$PWD/ecloop_amd/libecloop_hip.so
   for n in $FILTERS; do
-    ECLOOP_HIP_LIB=$path python3 bench.py --no-cpu --steps ${STEPS:-4} --warmup 1 --filter-n $n 2>/dev/null | python3 -c "
+    ECLOOP_HIP_LIB=$path python3 bench.py --no-cpu --no-secondary --steps ${STEPS:-4} --warmup 1 --filter-n $n 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.readlines()[-1])
 print('%-34s filter-n %-11s %9.1f Mkeys/s  %8.3f ms/launch' % ('$lib', '$n', r['value'], r['roofline']['ms_per_launch']))"

@@ -34,7 +34,7 @@ for n in 10000000 1100000000; do
              "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum"; do
     i=$((i+1))
     ECL_HIP_SKIP_SELFTEST=1 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/p$i" -o p -- \
-        python "$R/bench.py" --steps 1 --warmup 0 --no-cpu --filter-n $n > "$O/p$i.log" 2>&1
+        python "$R/bench.py" --steps 1 --warmup 0 --no-cpu --no-secondary --filter-n $n > "$O/p$i.log" 2>&1
     echo "# pass $i: --pmc $set" >> "$out"
     summ "$O/p$i" >> "$out"
     grep -m1 '"value"' "$O/p$i.log" | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('BENCH_mkeys', r['value'])" >> "$out" 2>/dev/null
