@@ -15,7 +15,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libecloop_hip.so")
 ASM = os.path.join(PKG, "libecloop_hip.gfx950.s")  # assembly of the library's code object (kept by the build)
-SOURCES = ["ecloop_hip.hip", "add_kernel.h", "hash160.h", "fe256.h", "ec.h", "bloom.h", "scalar_host.h"]
+SOURCES = ["ecloop_hip.hip", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
+           "bloom.h", "scalar_host.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 HOST_SOURCES = ["ecloop_hip_cli.c"]
 HOST_FLAGS = ["-O2", "-std=gnu11", "-Wall"]

@@ -1,0 +1,421 @@
+// abi_mul.h - host side of ecl_hip_mul_batch / _raw / _verify: window tables (built, checked, shared per device), staging, the piece
+// pipeline.  (one translation unit: included by ecloop_hip.hip after the context and the add path)
+#pragma once
+// ec_gtable_init (lib/ecc.c:880-905) on the device: every slot is an independent double-and-add
+static int ensure_gtable(ecl_hip* h) {
+  if (h->d_gtab) return ECL_OK;
+  const size_t slots = (size_t)GT_WINDOWS * GT_PER;
+  std::vector<u32> ks(slots * 8);
+  for (u32 w = 0; w < GT_WINDOWS; ++w) {
+    u256 base = sc_pow2(w * GT_W), cur = base;
+    for (u32 b = 1; b <= GT_PER; ++b) {
+      words_of(&ks[((size_t)w * GT_PER + b - 1) * 8], cur);
+      cur = sc_add(cur, base);
+    }
+  }
+  u32* d_k = nullptr;
+  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&h->d_gtab, slots * 16 * sizeof(u32)));
+  HIPCHK(h, hipMemcpy(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_mul_g, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, h->stream, d_k, h->d_gtab, (u8*)nullptr, (u32)slots);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(d_k));
+  return ECL_OK;
+}
+
+// `mul`'s window tables (see k_gtable_rows): built once per (device, width) and process, shared by every context on that
+// device that uses the width (the host program runs two per GPU), freed with the last of them.  Before a table is handed
+// out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
+// are compared with the double-and-add kernel.
+#define MUL_W_MIN 8u
+#define MUL_W_MAX 26u  /* 10 rows x 2^26 points: 43 GB */
+#define MUL_W_START 20u               /* 13 rows x 2^20 points, 809 MB: first call 48 ms against 41 ms at 14 bits and 47 at 18 */
+#define MUL_W_LONG 22u                /* 12 rows x 2^22 points, 3.0 GB: ~50 ms */
+#define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: at 955 vs 1006 M scalars/s the
+                                         wider table gains 0.05 ns per scalar, so its build is paid back after 10^9 of them */
+struct multab_t {
+  u32* d = nullptr;
+  int refs = 0;
+  std::mutex mu;  // held while the table is built: a context that wants the same table waits for it, one that wants another width does not
+};
+static std::mutex g_multab_mu;  // guards the map only (its nodes stay where they are)
+static std::map<std::pair<int, u32>, multab_t> g_multab;
+static multab_t* multab_entry(int dev, u32 W) {
+  std::lock_guard<std::mutex> lk(g_multab_mu);
+  return &g_multab[{dev, W}];
+}
+
+static void release_multable(ecl_hip* h) {
+  if (!h->d_multab) return;
+  multab_t* t = multab_entry(h->dev, h->multab_W);
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (--t->refs == 0) (void)hipFree(t->d), t->d = nullptr;
+  h->d_multab = nullptr, h->multab_W = 0;
+}
+
+static int build_multable(ecl_hip* h, u32 W, u32** out) {
+  dbuf<u32> lad_k, lad, tmp, tab, got, want, want_k;
+  dbuf<u64> slots;
+  const wtab tb = wtab_make(nullptr, W);
+  // ladders: 2^j * 2^(W w) * G for j < the row's digit width
+  std::vector<u32> ks((size_t)tb.nwin * 32 * 8, 0);
+  for (u32 w = 0; w < tb.nwin; ++w)
+    for (u32 j = 0; j < W && W * w + j < 256; ++j) words_of(&ks[((size_t)w * 32 + j) * 8], sc_pow2(W * w + j));
+  const u32 nlad = tb.nwin * 32;
+  HIPCHK(h, hipMalloc(&lad_k.p, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&lad.p, (size_t)nlad * 16 * sizeof(u32)));
+  HIPCHK(h, hipMemcpyAsync(lad_k.p, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_mul_g, dim3((nlad + 63) / 64), dim3(64), 0, h->stream, lad_k.p, lad.p, (u8*)nullptr, nlad);
+  HIPCHK(h, hipGetLastError());
+  // rows: launches of ~2^18 threads (one thread per 16 entries), the parking space of one launch reused by the next
+  const u32 nt = (tb.per + 15u) / 16u;
+  u32 rows = (1u << 18) / nt;
+  rows = rows < 1 ? 1 : (rows > tb.nwin ? tb.nwin : rows);
+  HIPCHK(h, hipMalloc(&tmp.p, (size_t)rows * 16 * 36 * nt * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&tab.p, wtab_slots(tb) * 16 * sizeof(u32)));
+  for (u32 w0 = 0; w0 < tb.nwin; w0 += rows) {
+    const u32 ny = tb.nwin - w0 < rows ? tb.nwin - w0 : rows;
+    hipLaunchKernelGGL(k_gtable_rows, dim3((nt + 255) / 256, ny), dim3(256), 0, h->stream, lad.p, tab.p, tmp.p, nt, W, w0);
+  }
+  HIPCHK(h, hipGetLastError());
+  // the check
+  const u32 PERW = 48;
+  std::vector<u64> sl;
+  std::vector<u32> wk;
+  u64 z = 0xD1B54A32D192ED03ull;
+  for (u32 w = 0; w < tb.nwin; ++w) {
+    const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
+    for (u32 i = 0; i < PERW; ++i) {
+      z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+      const u32 b = i == 0 ? 1u : i == 1 ? count : i < 18 ? (i - 1u) : i < 34 ? (i - 17u) * 16u + (i & 1u) : (u32)(z % count) + 1u;
+      const u32 digit = b > count ? count : b;
+      sl.push_back((u64)w * tb.per + digit - 1);
+      u32 kw[8];
+      words_of(kw, sc_mul_u64(sc_pow2(W * w), digit));
+      wk.insert(wk.end(), kw, kw + 8);
+    }
+  }
+  const u32 ns = (u32)sl.size();
+  HIPCHK(h, hipMalloc(&slots.p, (size_t)ns * 8));
+  HIPCHK(h, hipMalloc(&got.p, (size_t)ns * 64));
+  HIPCHK(h, hipMalloc(&want.p, (size_t)ns * 64));
+  HIPCHK(h, hipMalloc(&want_k.p, (size_t)ns * 32));
+  HIPCHK(h, hipMemcpyAsync(slots.p, sl.data(), (size_t)ns * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(want_k.p, wk.data(), (size_t)ns * 32, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_gather_slots, dim3((ns + 63) / 64), dim3(64), 0, h->stream, tab.p, slots.p, got.p, ns);
+  hipLaunchKernelGGL(k_mul_g, dim3((ns + 63) / 64), dim3(64), 0, h->stream, want_k.p, want.p, (u8*)nullptr, ns);
+  HIPCHK(h, hipGetLastError());
+  std::vector<u32> a((size_t)ns * 16), b((size_t)ns * 16);
+  HIPCHK(h, hipMemcpyAsync(a.data(), got.p, a.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(b.data(), want.p, b.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (a != b) {
+    h->err = "mul window table disagrees with the double-and-add kernel";
+    return ECL_E_SELFTEST;
+  }
+  *out = tab.p, tab.p = nullptr;
+  return ECL_OK;
+}
+
+// the table of width W for this context.  The new table is acquired (built if nobody has it yet) BEFORE the one the context holds is
+// given back: a failed switch - no room for the wider table - leaves the context with the table it had, nothing to rebuild.
+static int ensure_multable(ecl_hip* h, u32 W) {
+  if (h->d_multab && h->multab_W == W) return ECL_OK;
+  multab_t* t = multab_entry(h->dev, W);
+  {
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (!t->d) {
+      const int rc = build_multable(h, W, &t->d);
+      if (rc != ECL_OK) return rc;
+    }
+    ++t->refs;
+  }
+  if (h->d_multab) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // kernels of earlier calls may still read the old table
+    release_multable(h);
+  }
+  h->d_multab = t->d, h->multab_W = W;
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_set_mul_window(ecl_hip* h, uint32_t bits) {
+  if (!h || (bits != 0 && (bits < MUL_W_MIN || bits > MUL_W_MAX))) return ECL_E_ARG;
+  h->mul_W_fixed = bits;
+  return ECL_OK;
+}
+extern "C" int ecl_hip_get_mul_window(ecl_hip* h, uint32_t* bits) {
+  if (!h || !bits) return ECL_E_ARG;
+  *bits = h->multab_W;
+  return ECL_OK;
+}
+
+// what a mul_batch of n scalars needs before its first copy: the window table of the width in force, the copy stream and
+// its events, the device staging for one chunk (x2: the copy engine runs one chunk ahead of the kernel) and the parking
+// space of one chunk - sized to the call, grown on demand
+static int mul_setup(ecl_hip* h, u32 n, u32 W) {
+  int rc;
+  if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
+  if (!h->copy_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+    }
+  }
+  u32 want = 1u << 16;
+  while (want < MUL_CHUNK && want < n) want <<= 1;
+  if (want > h->kbuf_cap) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    for (int i = 0; i < 2; ++i) {
+      if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
+      if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
+      h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
+    }
+    h->pin_cap = 0;
+    if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
+    h->d_multmp = nullptr, h->kbuf_cap = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
+    // the kernel indexes the planes as r * 36 * nt + plane * nt + t with nt = ceil(m / R) rounded up to whole workgroups:
+    // up to R * 256 slots more than m
+    HIPCHK(h, hipMalloc(&h->d_multmp, ((size_t)want + MUL_R * 256u) * 36 * sizeof(u32)));
+    h->kbuf_cap = want;
+  }
+  return ECL_OK;
+}
+// window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
+static u32 mul_window_for(const ecl_hip* h, u32 n) {
+  return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER && !h->mul_long_failed ? MUL_W_LONG : MUL_W_START);
+}
+// mul_setup at the width in force; if the automatic choice was the long table and there is no room for it (3.6 GB while it is
+// built), the context stays on the short one for good.  Shared by ecl_hip_mul_batch, ecl_hip_mul_batch_raw and ecl_hip_reserve_mul.
+static int mul_setup_auto(ecl_hip* h, u32 n, u32* W_used) {
+  u32 W = mul_window_for(h, n);
+  int rc = mul_setup(h, n, W);
+  if (rc == ECL_E_HIP && !h->mul_W_fixed && W == MUL_W_LONG) {
+    (void)hipGetLastError();
+    h->mul_long_failed = true, W = MUL_W_START;
+    rc = mul_setup(h, n, W);
+  }
+  *W_used = W;
+  return rc;
+}
+
+extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
+  if (!h || n == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = ensure_found(h, raw_cap_of(h, cap ? cap : 1) + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  u32 W;
+  return mul_setup_auto(h, n, &W);
+}
+
+extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
+                                 uint32_t* nout) {
+  if (!h || (!scalars && n) || (!out && cap) || !nout) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  u32 W;
+  if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
+  const wtab gtab = wtab_make(h->d_multab, W);
+  h->mul_seen += n;
+  // Scalars in page-locked host memory (ecl_hip_alloc_host / ecl_hip_pin_host) go to the device by DMA straight from the
+  // caller's array; pageable ones are first copied into two pinned staging buffers - a single-threaded memcpy that caps
+  // the call near 18 GB/s = 570 M scalars/s (measured), below what the kernel takes.
+  bool direct = false;
+  {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof attr);
+    if ((size_t)n * 32 >= ECL_PIN_MIN_BYTES) {  // small batches are staged whatever their memory is
+      if (hipPointerGetAttributes(&attr, scalars) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+      else (void)hipGetLastError();
+    }
+  }
+  if (!direct)
+    for (int i = 0; i < 2; ++i)
+      if (!h->pin_k[i] || h->pin_cap < h->kbuf_cap) {
+        if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
+        h->pin_k[i] = nullptr;
+        HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)h->kbuf_cap * 32, hipHostMallocDefault));
+        if (i == 1) h->pin_cap = h->kbuf_cap;
+      }
+  add_args a;
+  memset(&a, 0, sizeof a);
+  a.bloom = bloom_make(h->d_bloom, h->bloom_words);
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
+  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
+  // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
+  // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel: a first piece of 2^18 scalars (nothing
+  // overlaps its copy), then pieces of 2^20, or 2^21 for calls of 2^25 scalars and more.  Kernel time per piece on 2^26-scalar calls
+  // (tools/mul_kernel_times.sh, profiles/r04_mul_ab.txt): 2^20 scalars (8 per thread) 0.977 ms = 1.07 G scalars/s, 2^21 (16 per
+  // thread) 1.850 ms = 1.13 G/s, 2^22 (32 per thread) 3.999 ms = 1.05 G/s - sharing the inversion among more scalars stops paying at
+  // 16 per thread (the parked sums of a piece no longer stay in the Infinity Cache: 604 MB at 2^22), and a long piece lengthens the
+  // pipeline's fill and drain.  Pieces that double (2^18 ... 2^22): 932 M scalars/s on 2^24-scalar calls against 1007 - with two
+  // staging buffers the copy of piece c + 1 starts when the kernel of piece c - 1 ends, and a piece twice as long as the last does
+  // not arrive in time.  Fewer than 2^17 threads per kernel cost more than they save; 196 608 or 262 144 threads do too (829 / 1075
+  // against 1097 M scalars/s).
+  static const u32 first_log2 = getenv("ECL_HIP_MUL_FIRST") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST")) : 18u;   // tuning hooks (A/B runs)
+  static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 1600u;
+  static const u32 top_fixed = getenv("ECL_HIP_MUL_TOP") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP")) : 0u;
+  const u32 top_log2 = top_fixed ? top_fixed : (n >= (1u << 25) ? 21u : 20u);
+  const u32 top = h->kbuf_cap < (1u << top_log2) ? h->kbuf_cap : 1u << top_log2;
+  u32 lim = top < (1u << first_log2) ? top : 1u << first_log2;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
+    const u32 b = c & 1;
+    m = n - at < lim ? n - at : lim;
+    if (c >= 2) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel two chunks back is done with this pair
+    const void* src = scalars[at];
+    if (!direct) memcpy(h->pin_k[b], scalars[at], (size_t)m * 32), src = h->pin_k[b];
+    HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
+    // scalars per thread: as many as keep >= 2^17 threads in flight (two waves per SIMD hide the table gathers; the host
+    // program keeps two contexts per GPU busy, which fills the other half), at most MUL_R
+    static const u32 nt_target = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 1u << 17;  // tuning hook (A/B runs)
+    u32 R = m / nt_target;
+    R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
+    const u32 nt = ((m + R - 1) / R + 255u) & ~255u;  // whole workgroups: every row of scalars and every parking plane starts on a 1 KiB boundary
+    dim3 grid(nt / 256), blk(256);
+    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  u32 cnt = 0;
+  rc = collect_found(h, cap, rcap, out, &cnt, false);
+  *nout = cnt;
+  if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));  // copies + kernels of this call, as the stream saw them
+    h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
+  }
+  return rc;
+}
+
+// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests.  One chunk per call (the caller
+// cuts: n <= 2^22 lines); text and line table cross PCIe on the copy stream, hashing and the window sums follow on the
+// context's stream.  Two contexts per GPU overlap one call's copies with the other's kernels, as for ecl_hip_mul_batch.
+extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t text_bytes, const uint64_t* lines, uint32_t n, ecl_found* out,
+                                     uint32_t cap, uint32_t* nout) {
+  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_CHUNK || text_bytes > 0xFFFFFFF0u) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (n == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  const u32 rcap = raw_cap_of(h, cap ? cap : 1);
+  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  u32 W;
+  if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
+  const wtab gtab = wtab_make(h->d_multab, W);
+  h->mul_seen += n;
+  const size_t text_words = ((size_t)text_bytes + 3) / 4 + 2;  // two spare words: the gather reads one word past the last byte
+  if (text_words > h->rawtext_cap || n > h->rawlines_cap) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    if (text_words > h->rawtext_cap) {
+      if (h->d_rawtext) HIPCHK(h, hipFree(h->d_rawtext));
+      h->d_rawtext = nullptr, h->rawtext_cap = 0;
+      size_t capw = (size_t)1 << 22;  // 16 MB of text
+      while (capw < text_words) capw <<= 1;
+      HIPCHK(h, hipMalloc(&h->d_rawtext, capw * 4));
+      // (hipMemset is asynchronous to the host and runs on the legacy stream, which the context's non-blocking streams do not
+      // wait for: the clearing goes on the copy stream, in front of the text that is copied there next)
+      HIPCHK(h, hipMemsetAsync(h->d_rawtext, 0, capw * 4, h->copy_stream));
+      h->rawtext_cap = capw;
+    }
+    if (n > h->rawlines_cap) {
+      if (h->d_rawlines) HIPCHK(h, hipFree(h->d_rawlines));
+      h->d_rawlines = nullptr, h->rawlines_cap = 0;
+      u32 capl = 1u << 20;
+      while (capl < n) capl <<= 1;
+      HIPCHK(h, hipMalloc(&h->d_rawlines, (size_t)capl * 8));
+      h->rawlines_cap = capl;
+    }
+  }
+  add_args a;
+  memset(&a, 0, sizeof a);
+  a.bloom = bloom_make(h->d_bloom, h->bloom_words);
+  a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 3 * sizeof(u32), h->stream));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_rawtext, text, text_bytes, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_rawlines, lines, (size_t)n * 8, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
+  hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
+  u32 R = n >> 17;
+  R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
+  const u32 nt = ((n + R - 1) / R + 255u) & ~255u;
+  dim3 grid(nt / 256), blk(256);
+  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  u32 cnt = 0;
+  rc = collect_found(h, cap, rcap, out, &cnt, false);
+  *nout = cnt;
+  u32 bad = 0;
+  HIPCHK(h, hipMemcpy(&bad, h->d_counter + 2, sizeof bad, hipMemcpyDeviceToHost));
+  if (bad) {
+    h->err = "mul_batch_raw: a line of the table lies outside the text";
+    *nout = 0;
+    return ECL_E_ARG;
+  }
+  if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->mul_ms += ms, h->mul_calls += 1, h->mul_scalars += n;
+  }
+  return rc;
+}
+
+extern "C" int ecl_hip_verify(ecl_hip* h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h33)[5], uint32_t (*h65)[5], uint8_t* ok) {
+  if (!h || !k || !h33 || !h65 || !ok || n == 0 || n > (1u << 31)) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc;
+  if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
+  if (n > h->ver_cap) {  // grow-only device staging: scalars 32 B, two hashes 20 B each, flag
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_ver) HIPCHK(h, hipFree(h->d_ver));
+    h->d_ver = nullptr, h->ver_cap = 0;
+    u32 cap = 256;
+    while (cap < n) cap <<= 1;
+    HIPCHK(h, hipMalloc(&h->d_ver, (size_t)cap * 76));
+    h->ver_cap = cap;
+  }
+  u8* base = (u8*)h->d_ver;
+  u32* dk = (u32*)base;
+  u32* d33 = (u32*)(base + (size_t)h->ver_cap * 32);
+  u32* d65 = (u32*)(base + (size_t)h->ver_cap * 52);
+  u8* dok = base + (size_t)h->ver_cap * 72;
+  HIPCHK(h, hipMemcpyAsync(dk, k, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_verify, dim3((n + 63) / 64), dim3(64), 0, h->stream, dk, n, h->d_gtab, d33, d65, dok);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h33, d33, (size_t)n * 20, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h65, d65, (size_t)n * 20, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return ECL_OK;
+}
+
+extern "C" int ecl_hip_get_mul_timing(ecl_hip* h, double* ms, uint64_t* calls, uint64_t* scalars) {
+  if (!h) return ECL_E_ARG;
+  if (ms) *ms = h->mul_ms;
+  if (calls) *calls = h->mul_calls;
+  if (scalars) *scalars = h->mul_scalars;
+  return ECL_OK;
+}

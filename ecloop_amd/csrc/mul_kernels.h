@@ -1,0 +1,345 @@
+// mul_kernels.h - the `mul` command on the device: window tables of any width, window sums, batched normalisation + hash160 + probe,
+// SHA-256 of raw lines, the window-table forms of a single scalar multiplication (base centre of a walk, pk_verify_hash).
+// (one translation unit: included by ecloop_hip.hip)
+#pragma once
+#include "add_kernel.h"
+#include "ec.h"
+// `mul` command body (main.c:530-534, 458-479): public key of each scalar by the fixed-base window method of
+// ec_gtable_mul (lib/ecc.c:876-929: W = 14, 19 windows, table slot (2^14-1)*i + b-1 = b * 2^(14 i) * G), then
+// ec_jacobi_grprdc (lib/ecc.c:695-707: ONE inversion for the whole batch), then hash + probe.
+// <= 19 mixed additions of table points per scalar (64-byte gathers, the 19.9 MB table lives in L2 / Infinity Cache).
+// The scalar 0 (mod n) yields no point (the reference emits garbage).
+#define GT_W 14u
+#define MUL_CHUNK (1u << 22)  /* scalars per staged chunk of ecl_hip_mul_batch (128 MB): 2^18 threads x MUL_R */
+#define GT_WINDOWS 19u
+#define GT_PER ((1u << GT_W) - 1u)
+// k*G as a sum of table points, one per non-zero W-bit digit of k (LSB-first windows, ec_gtable_mul lib/ecc.c:907-929):
+// slot PER*w + b-1 = b * 2^(W w) * G with PER = 2^W - 1, canonical x[8], y[8] words per slot.
+template <u32 W, u32 NWIN>
+__device__ __forceinline__ jac gtable_sum(const u32 kk[9], const u32* __restrict__ gtab) {
+  constexpr u32 PER = (1u << W) - 1u;
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#pragma unroll 1
+  for (u32 w = 0; w < NWIN; ++w) {
+    const u32 bit = w * W, word = bit >> 5, sh = bit & 31;
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
+      if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+    }
+    const u32 digit = (u32)((((u64)hi << 32 | lo) >> sh) & PER);
+    if (!digit) continue;
+    const u32* e = gtab + ((size_t)w * PER + digit - 1) * 16;
+    acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
+  }
+  return acc;
+}
+__device__ __forceinline__ jac gtable_mul(const u32 kk[9], const u32* __restrict__ gtab) { return gtable_sum<GT_W, GT_WINDOWS>(kk, gtab); }
+
+// ---- `mul` has its own window tables, sized for HBM.  The reference's W = 14 (19 windows, 19.9 MB) is sized for a CPU's
+// cache (lib/ecc.c:876, `bench-gtable` sweeps it); on a 288 GB part W = 22 costs 3.0 GB and turns 19 additions per
+// scalar into 12 (one per non-zero digit).  Same method, same results; measured on 2^24-scalar calls, -a cu, device
+// time: W = 14 725 M scalars/s, 16 811, 18 842, 20 878, 22 919, 24 (11.8 GB) 965 (profiles/r03_mul_w_sweep.txt).
+// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 20, 809 MB,
+// and moves to W = 22 once it has seen enough scalars to pay for the 50 ms build: ecl_hip_mul_batch).
+// The rows are not built by millions of double-and-add ladders but the way the walk's lane centres are: row w is
+// P_w, 2 P_w, 3 P_w, ... with P_w = 2^(W w) G - the points C0 + g D of k_init_centres_batched with C0 = D = P_w -
+// 44 multiplications per entry, one inversion per 16 entries; the ladder points 2^j P_w of every row come from one
+// k_mul_g launch.
+struct wtab {
+  const u32* p;  // slot per * w + b - 1 = b * 2^(W w) * G, canonical x[8], y[8]
+  u32 W, nwin, per, top_per;  // bits per window, windows = ceil(256 / W), 2^W - 1, entries of the last row
+};
+__host__ __device__ inline wtab wtab_make(const u32* p, u32 W) {
+  wtab t;
+  t.p = p, t.W = W, t.nwin = (256u + W - 1u) / W, t.per = (1u << W) - 1u;
+  t.top_per = (1u << (256u - W * (t.nwin - 1u))) - 1u;
+  return t;
+}
+__host__ __device__ inline size_t wtab_slots(const wtab& t) { return (size_t)(t.nwin - 1u) * t.per + t.top_per; }
+#ifndef ECL_WTAB_PREFETCH
+#define ECL_WTAB_PREFETCH 1  /* 0: load a window's point when it is added (A/B) */
+#endif
+__device__ __forceinline__ u32 wtab_digit(const u32 kk[9], const wtab& t, u32 w) {
+  const u32 bit = w * t.W, word = bit >> 5, sh = bit & 31;
+  u32 lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
+    if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
+  }
+  return (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // kk[8] = 0: the last window is as narrow as it is
+}
+// The point of window w + 1 is requested before the addition of window w's (64 bytes, 16 registers held across one
+// mixed addition): the gathers come from HBM / Infinity Cache and the kernel runs at two waves per SIMD, too few to hide them.
+// Measured on 2^24-scalar calls, 22-bit table, four processes each: 995-1001 M scalars/s with, 980-985 without.
+__device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+#if ECL_WTAB_PREFETCH
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  u32 dnext = wtab_digit(kk, t, 0);
+  if (dnext) {
+    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = dnext;
+    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    if (dnext) {
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+    }
+    if (!digit) continue;
+    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    acc = jac_madd(acc, fe_from_words(xw), fe_from_words(yw));
+  }
+#else
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = wtab_digit(kk, t, w);
+    if (!digit) continue;
+    const u32* e = t.p + ((size_t)w * t.per + digit - 1) * 16;
+    acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
+  }
+#endif
+  return acc;
+}
+#ifndef ECL_MUL_MMADD
+#define ECL_MUL_MMADD 1  /* A/B: 0 = the second point goes through the general mixed addition too (one code body less) */
+#endif
+// the complete sum out of line: the fallback of a scalar whose lazy sum ended with Z = 0 (never taken by a random scalar)
+__device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { return wtab_sum(kk, t); }
+// The same sum for k_mul_check's hot loop: lazy additions without exceptional cases (ec.h: jac_madd_lazy; the caller tests Z once
+// at the end), the second point of a sum added to the first as affine + affine (4M + 2S instead of 8M + 3S).  State: npts = 0
+// nothing yet, 1 = one table point held as it is (acc.X, acc.Y), >= 2 = Jacobian.  Returns with acc.inf = 1 for an all-zero scalar
+// and acc.Z = 1 for a single point.
+__device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
+  jac acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
+  u32 npts = 0;
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  u32 dnext = wtab_digit(kk, t, 0);
+  if (dnext) {
+    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = dnext;
+    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    if (dnext) {
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+    }
+    if (!digit) continue;
+    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
+    if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
+#if ECL_MUL_MMADD
+    else if (npts == 1) acc = jac_mmadd_lazy(acc.X, acc.Y, qx, qy);
+#endif
+    else acc = jac_madd_lazy(acc, qx, qy);
+    ++npts;
+  }
+  return acc;
+}
+// rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
+// consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
+__global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
+                                                      u32 W, u32 w0) {
+  const wtab tb = wtab_make(table, W);
+  const u32 w = w0 + blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
+  const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
+  const u32 g0 = t * 16u;
+  if (t >= nt || g0 >= count) return;
+  const u32* ladder = ladders + (size_t)w * 32 * 16;
+  u32* out = table + (size_t)w * tb.per * 16;
+  u32* tmp = tmp_all + (size_t)blockIdx.y * 16 * 36 * nt;
+  jac acc;
+  acc.X = fe_ldw(ladder), acc.Y = fe_ldw(ladder + 8), acc.Z = fe_one(), acc.inf = 0;
+#pragma unroll 1
+  for (int j = 4; j < 32; ++j) {
+    if ((g0 >> j) == 0) break;
+    if ((g0 >> j) & 1u) acc = jac_madd(acc, fe_ldw(ladder + j * 16), fe_ldw(ladder + j * 16 + 8));
+  }
+  const fe dx = fe_ldw(ladder), dy = fe_ldw(ladder + 8);
+  fe prod = fe_one();
+#pragma unroll 1
+  for (u32 r = 0; r < 16u; ++r) {
+    if (r) acc = jac_madd(acc, dx, dy);
+    const fe z = acc.inf ? fe_one() : acc.Z;
+    u32* p = tmp + (size_t)r * 36 * nt + t;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      p[(size_t)l * nt] = acc.X.n[l], p[(size_t)(9 + l) * nt] = acc.Y.n[l];
+      p[(size_t)(18 + l) * nt] = z.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+    }
+    prod = fe_mul(prod, z);
+  }
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = 16u; r-- > 0;) {
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, Z, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      Z.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe zi = fe_mul(inv, pre);
+    inv = fe_mul(inv, Z);
+    if (g0 + r >= count) continue;
+    const fe zi2 = fe_sqr(zi);
+    fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
+    fe_normalize(x), fe_normalize(y);
+    u32 xw[8], yw[8];
+    fe_to_words(xw, x), fe_to_words(yw, y);
+    uint4* o = (uint4*)(out + (size_t)(g0 + r) * 16);
+    o[0] = make_uint4(xw[0], xw[1], xw[2], xw[3]), o[1] = make_uint4(xw[4], xw[5], xw[6], xw[7]);
+    o[2] = make_uint4(yw[0], yw[1], yw[2], yw[3]), o[3] = make_uint4(yw[4], yw[5], yw[6], yw[7]);
+  }
+}
+// copies chosen slots of the table out for the bring-up check against the double-and-add kernel
+__global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restrict__ slot, u32* __restrict__ out, u32 n) {
+  const u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  const uint4* s = (const uint4*)(table + slot[i] * 16);
+  uint4* o = (uint4*)(out + (size_t)i * 16);
+  o[0] = s[0], o[1] = s[1], o[2] = s[2], o[3] = s[3];
+}
+// One thread owns MUL_R scalars (i = t, t + nt, ...: a wave reads 2 KiB of contiguous scalars per round): their window
+// sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
+// per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
+// the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
+#define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
+template <bool A33, bool A65>
+__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
+                                                   u32* __restrict__ tmp, u32 nt, u32 R) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nt) return;
+  fe prod = fe_one();
+  u32 infmask = 0;
+#pragma unroll 1
+  for (u32 r = 0; r < R; ++r) {
+    const u32 i = r * nt + t;
+    if (i >= n) break;
+    u32 kk[9];
+    const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
+    kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
+    jac acc = wtab_sum_lazy(kk, gtab);
+    // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves Z = 0, and a zero in
+    // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
+    if (!acc.inf && __builtin_expect(fe_is_zero(acc.Z), 0)) acc = wtab_sum_complete(kk, gtab);
+    const fe z = acc.inf ? fe_one() : acc.Z;
+    infmask |= (acc.inf ? 1u : 0u) << r;
+    u32* p = tmp + (size_t)r * 36 * nt + t;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      p[(size_t)l * nt] = acc.X.n[l], p[(size_t)(9 + l) * nt] = acc.Y.n[l];
+      p[(size_t)(18 + l) * nt] = z.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+    }
+    prod = fe_mul(prod, z);
+  }
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = R; r-- > 0;) {
+    const u32 i = r * nt + t;
+    if (i >= n) continue;
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, Z, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      Z.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe zi = fe_mul(inv, pre);
+    inv = fe_mul(inv, Z);
+    if ((infmask >> r) & 1u) continue;
+    const fe zi2 = fe_sqr(zi);
+    const fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
+    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
+  }
+}
+// `mul -raw` (main.c:505-527): the scalar of a line is the SHA-256 of its bytes.  One lane per line: the line's bytes are
+// gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and
+// compressed block by block; the digest, read as a big-endian 256-bit number, is written where k_mul_check expects the
+// scalar (8 little-endian words).  lines[i] = start | length << 32, offsets into `text`; `text` carries 8 spare bytes.
+__global__ void __launch_bounds__(256) k_raw_scalars(const u32* __restrict__ text, u32 text_bytes, const u64* __restrict__ lines, u32 n, u32* __restrict__ out,
+                                                      u32* __restrict__ bad) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 ln = lines[i];
+  const u32 start = (u32)ln;
+  u32 L = (u32)(ln >> 32);
+  if ((u64)start + L > text_bytes) *bad = 1, L = 0;  // a line outside the text: the call is refused (ECL_E_ARG), nothing is read there
+  u32 st[8];
+  sha256_init(st);
+  const u32 nblk = (L + 9u + 63u) >> 6;
+#pragma unroll 1
+  for (u32 b = 0; b < nblk; ++b) {
+    u32 w[16];
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) {
+      const u32 pos = 64u * b + 4u * j;
+      u32 v = 0;
+      if (pos < L) {
+        const u32 at = start + pos, sh = (at & 3u) * 8u;
+        const u32 lo = text[at >> 2], hi = text[(at >> 2) + 1];
+        const u32 raw = (u32)((((u64)hi << 32) | lo) >> sh);  // the four bytes at `at`, first byte lowest
+        v = __builtin_bswap32(raw);
+        const u32 have = L - pos;
+        if (have < 4u) v &= ~(0xFFFFFFFFu >> (8u * have));
+      }
+      if (pos <= L && L - pos < 4u) v |= 0x80000000u >> (8u * (L - pos));
+      w[j] = v;
+    }
+    if (b == nblk - 1u) w[14] = L >> 29, w[15] = L << 3;
+    sha256_compress(st, w);
+  }
+  uint4* o = (uint4*)(out + (size_t)i * 8);
+  o[0] = make_uint4(st[7], st[6], st[5], st[4]), o[1] = make_uint4(st[3], st[2], st[1], st[0]);
+}
+// k*G of ONE scalar (kernel argument) through the window table: the base centre of a non-contiguous add call.
+// 19 mixed additions + one inversion (~0.1 ms) instead of the 256-step double-and-add of k_mul_g (~1.2 ms of latency).
+struct scalar_arg { u32 w[8]; };
+__global__ void __launch_bounds__(64) k_mul_window_one(scalar_arg s, const u32* __restrict__ gtab, u32* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 kk[9];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = s.w[w];
+  kk[8] = 0;
+  fe x, y;
+  jac_to_affine(x, y, gtable_mul(kk, gtab));  // never infinity: the range check excludes the scalar 0
+  u32 xw[8], yw[8];
+  fe_to_words(xw, x), fe_to_words(yw, y);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) out[w] = xw[w], out[8 + w] = yw[w];
+}
+
+// pk_verify_hash (main.c:248-263) for the hits of a call: re-derive each reported private key's public key on a path
+// that shares nothing with the walk (fixed-base window sum over the table that the double-and-add kernel built, own
+// inversion per key) and hash it both ways.  One lane per key; ~0.15 ms whatever the count (the walk's hits are few).
+__global__ void __launch_bounds__(64) k_verify(const u32* __restrict__ k, u32 n, const u32* __restrict__ gtab, u32* __restrict__ h33,
+                                               u32* __restrict__ h65, u8* __restrict__ ok) {
+  const u32 i = blockIdx.x * 64u + threadIdx.x;
+  if (i >= n) return;
+  u32 kk[9];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) kk[w] = k[(size_t)i * 8 + w];
+  kk[8] = 0;
+  fe x, y;
+  const int fin = jac_to_affine(x, y, gtable_mul(kk, gtab));
+  u32 xw[8], yw[8], h[5];
+  fe_to_words(xw, x), fe_to_words(yw, y);
+  hash160_33(h, xw, yw[0] & 1u);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h33[(size_t)i * 5 + w] = h[w];
+  hash160_65(h, xw, yw);
+#pragma unroll
+  for (int w = 0; w < 5; ++w) h65[(size_t)i * 5 + w] = h[w];
+  ok[i] = (u8)fin;
+}
