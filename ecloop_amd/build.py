@@ -18,7 +18,8 @@ ASM = os.path.join(PKG, "libecloop_hip.gfx950.s")  # assembly of the library's c
 SOURCES = ["ecloop_hip.hip", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
            "bloom.h", "scalar_host.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
-HOST_SOURCES = ["ecloop_hip_cli.c"]
+HOST_SOURCES = ["ecloop_hip_cli.c"]  # the translation unit; its parts (hashed for the stamp like it):
+HOST_PARTS = ["cli_base.h", "cli_filter.h", "cli_report.h", "cli_add.h", "cli_mul.h", "cli_rnd_blf.h", "cli_extras.h"]
 HOST_FLAGS = ["-O2", "-std=gnu11", "-Wall"]
 
 
@@ -27,7 +28,7 @@ def _library_sources():
 
 
 def _host_sources():
-    return [os.path.join(PKG, "host", s) for s in HOST_SOURCES] + [os.path.join(ROOT, "include", "ecloop_hip.h")]
+    return [os.path.join(PKG, "host", s) for s in HOST_SOURCES + HOST_PARTS] + [os.path.join(ROOT, "include", "ecloop_hip.h")]
 
 
 def _sha256_of(files, extra=()):

@@ -24,7 +24,8 @@ def main():
     ref = set()
     for f in glob.glob(os.path.join(REF, "*.c")) + glob.glob(os.path.join(REF, "lib", "*.c")):
         ref.update(t for _, t in lines(f))
-    files = sys.argv[1:] or [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ecloop_amd", "host", "ecloop_hip_cli.c")]
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ecloop_amd", "host")
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(host, "*.c")) + glob.glob(os.path.join(host, "*.h")))
     verbose = "-v" in files
     for f in [x for x in files if x != "-v"]:
         ls = lines(f)
