@@ -184,6 +184,15 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
   }
   return ECL_OK;
 }
+// threads and scalars per thread of one k_mul_check launch over m scalars: as many scalars per thread (one shared inversion, at most
+// MUL_R) as still keep 65536 x ECL_MUL_WAVES threads in flight - what the chip holds at once; a few blocks more would wait for a whole
+// round - in whole workgroups, so that every row of scalars and every parking plane starts on a 1 KiB boundary
+static void mul_geometry(u32 m, u32* R_out, u32* nt_out) {
+  static const u32 nt_target = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 65536u * ECL_MUL_WAVES;  // tuning hook (A/B runs)
+  u32 R = (m + nt_target - 1) / nt_target;
+  R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
+  *R_out = R, *nt_out = ((m + R - 1) / R + 255u) & ~255u;
+}
 // window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
 static u32 mul_window_for(const ecl_hip* h, u32 n) {
   return h->mul_W_fixed ? h->mul_W_fixed : (h->mul_seen + n >= MUL_LONG_AFTER && !h->mul_long_failed ? MUL_W_LONG : MUL_W_START);
@@ -278,12 +287,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-    // scalars per thread: as many as keep >= 2^17 threads in flight (two waves per SIMD hide the table gathers; the host
-    // program keeps two contexts per GPU busy, which fills the other half), at most MUL_R
-    static const u32 nt_target = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 1u << 17;  // tuning hook (A/B runs)
-    u32 R = m / nt_target;
-    R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
-    const u32 nt = ((m + R - 1) / R + 255u) & ~255u;  // whole workgroups: every row of scalars and every parking plane starts on a 1 KiB boundary
+    u32 R, nt;
+    mul_geometry(m, &R, &nt);
     dim3 grid(nt / 256), blk(256);
     if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
     else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
@@ -355,9 +360,8 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
   hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
-  u32 R = n >> 17;
-  R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
-  const u32 nt = ((n + R - 1) / R + 255u) & ~255u;
+  u32 R, nt;
+  mul_geometry(n, &R, &nt);
   dim3 grid(nt / 256), blk(256);
   const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
   if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);

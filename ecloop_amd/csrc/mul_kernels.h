@@ -216,8 +216,12 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
 #define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
+#ifndef ECL_MUL_WAVES
+#define ECL_MUL_WAVES 2  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side
+                            launches 65536 x ECL_MUL_WAVES threads per piece */
+#endif
 template <bool A33, bool A65>
-__global__ void __launch_bounds__(256) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
+__global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt) return;

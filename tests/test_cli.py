@@ -121,7 +121,8 @@ def test_add_sharded_over_device_threads(cli, tmp_path, ngpu, counter):
         assert len(calls) == ngpu and sum(calls) >= 1
         if not counter:  # static shards: whole 2048-key groups, ceil(hashed / N) per thread, one call each
             per = -(-(-(-hashed // ngpu)) // 2048) * 2048
-            assert sorted(calls, reverse=True) == [1] * -(-hashed // per) + [0] * (ngpu - -(-hashed // per)), (name, calls)
+            once = 2 if "ones" in args[1] else 1  # all-ones filter: the first try overflows the 4096-record buffer and is run again
+            assert sorted(calls, reverse=True) == [once] * -(-hashed // per) + [0] * (ngpu - -(-hashed // per)), (name, calls)
 
 
 @pytest.mark.gpu

@@ -1,12 +1,9 @@
 #!/bin/bash
-# round 4: `mul` A/B - lazy additions with / without the affine + affine first addition, 2 / 3 waves per SIMD, window widths
+# round 4: `mul` A/B - waves per SIMD of k_mul_check (launch bounds 2 / 3 / 4 = 256 / 168 / 128 VGPRs; 65536 threads per wave-per-SIMD),
+# with (w3, w4) and without (w3n, w4n) the affine + affine first addition
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out/r04f
+mkdir -p gpurun_out/r04j
 {
-echo "## default schedule, 2^24, 12 steps"; STEPS=12 bash tools/ab_mul.sh "22 24" build_ab/r04_mul_nommadd.so build_ab/r04_base.so
-echo "## default schedule, 2^26"; LOG2=26 STEPS=4 bash tools/ab_mul.sh "22 24" build_ab/r04_mul_nommadd.so build_ab/r04_base.so
-echo "## 3 waves per SIMD (196608 threads), 2^24 and 2^26"; ECL_HIP_MUL_NT=196608 STEPS=12 bash tools/ab_mul.sh "22" build_ab/r04_mul_nommadd.so
-ECL_HIP_MUL_NT=196608 LOG2=26 STEPS=4 bash tools/ab_mul.sh "22" build_ab/r04_mul_nommadd.so
-echo "## pieces of 2^21 from the second on, 2^24"; ECL_HIP_MUL_TOP=21 STEPS=12 bash tools/ab_mul.sh "22" build_ab/r04_mul_nommadd.so
-} 2>&1 | tee gpurun_out/r04f/mul_ab.txt
-bash tools/pmc_filter_ab.sh build_ab/r04_quarter.so build_ab/r04_waves2.so 2>&1 | tee gpurun_out/r04f/pmc_filter_ab.txt
+echo "## 2^24-scalar calls, 12 steps"; STEPS=12 bash tools/ab_mul.sh "22" build_ab/r04_mul_w3.so build_ab/r04_mul_w4.so build_ab/r04_mul_w3n.so build_ab/r04_mul_w4n.so build_ab/r04_base.so
+echo "## 2^26-scalar calls"; LOG2=26 STEPS=4 bash tools/ab_mul.sh "22" build_ab/r04_mul_w3.so build_ab/r04_mul_w4.so build_ab/r04_mul_w3n.so build_ab/r04_mul_w4n.so build_ab/r04_base.so
+} 2>&1 | tee gpurun_out/r04j/mul_waves.txt
