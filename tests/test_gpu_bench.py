@@ -38,6 +38,30 @@ def test_bench_line_single_gpu_small():
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], abs=2e-3)
 
 
+def test_bench_secondary_legs_at_reduced_size():
+    """the `secondary` object of the default N = 1 run (BASELINE configs[2], [3], [4] beside the headline), at sizes that finish in a
+    minute: every leg present, checked against the oracle on its sample (a mismatch makes bench.py exit non-zero), rates consistent"""
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--cfg2-keys-log2", "27",
+                         "--cfg2-steps", "1", "--cfg2-filter-n", "60000000", "--cfg3-windows", "1", "--cfg4-log2", "22", "--cfg4-steps", "2",
+                         "--cfg4-cli-log2", "22"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=ROOT)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    r = last_json(pr.stdout)
+    assert r["metric"] == "Mkeys/sec (add, addr33)" and r["config"]["keys_per_gpu_per_step"] == 1 << 32  # the headline is untouched
+    s = r["secondary"]
+    c2, c3, api, cli = s["cfg2"], s["cfg3"], s["cfg4"]["api"], s["cfg4"]["host_program"]
+    assert c2["config"]["hashes_per_key"] == 12 and c2["config"]["found_list_matches_oracle_on_sample"] and c2["config"]["planted_checked"] == 32
+    assert abs(c2["value"] - (1 << 27) / (c2["ms_per_step"] * 1e3)) / c2["value"] < 1e-3 and c2["value"] > 300
+    assert c2["roofline"]["kernel"] == "k_add<addr33,addr65,endo>" and c2["roofline"]["keys_per_launch"] == 1 << 27
+    assert c3["windows"] == 1 and c3["config"]["checked"] == 1 << 32 and c3["config"]["found_list_matches_oracle_on_sample"] and c3["value"] > 3000
+    assert 0 < c3["config"]["setup_share"] < 0.05
+    assert api["config"]["found_list_matches_oracle_on_sample"] and api["config"]["window_bits"] == 22 and api["value"] > 100
+    assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
+    assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
+    for leg in (c2, api):  # rooflines priced with the kernels' own PMC profiles when those are in the tree
+        if leg["roofline"].get("profile"):
+            assert leg["roofline"]["frac"] == pytest.approx(leg["roofline"]["achieved"] / leg["roofline"]["peak"], abs=2e-3)
+
+
 def check_two(r, launcher):
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["keys_per_gpu_per_step"] == 1 << 26
     assert launcher in r["config"]["launcher"]
