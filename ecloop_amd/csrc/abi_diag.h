@@ -5,7 +5,7 @@
 
 extern "C" int ecl_hip_diag_fe(ecl_hip* h, int op, const uint64_t (*a)[4], const uint64_t (*b)[4], uint64_t (*r)[4],
                                uint32_t n) {
-  if (!h || !a || !r || n == 0 || op < 0 || op > 8) return ECL_E_ARG;
+  if (!h || !a || !r || n == 0 || op < 0 || op > 11) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   size_t bytes = (size_t)n * 32;
   dbuf<u32> da, db, dr;

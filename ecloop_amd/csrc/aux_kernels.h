@@ -19,6 +19,10 @@ __global__ void k_diag_fe(int op, const u32* a, const u32* b, u32* r, u32 n) {
   // dropped-mask miscompile described in fe256.h
   case 6: z = fe_sqr(fe_sqr(x)); break;
   case 7: z = fe_mul(fe_mul(x, y), y); break;
+  // the two inversions (fe256.h): division steps and the addition chain of lib/ecc.c:463-520; 11: unnormalised input, 1 / (4y - 2x)
+  case 9: z = fe_inv_divsteps(x); break;
+  case 10: z = fe_inv_fermat(x); break;
+  case 11: z = fe_inv_divsteps(fe_add(fe_neg(fe_add(x, x), 2), fe_add(fe_add(y, y), fe_add(y, y)))); break;
   default: z = fe_mul(fe_sqr(x), x); break;
   }
   fe_normalize(z);

@@ -298,7 +298,7 @@ __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {
 }
 // a^(p-2): the 255 S + 15 M addition chain of lib/ecc.c:463-520 (x2,x3,x6,x9,x11,x22,x44,x88,x176,x220,x223).
 // Input magnitude <= 2, output magnitude 1.
-__host__ __device__ __noinline__ inline fe fe_inv(const fe& a) {
+__host__ __device__ __noinline__ inline fe fe_inv_fermat(const fe& a) {
   fe x2 = fe_mul(fe_sqr(a), a);
   fe x3 = fe_mul(fe_sqr(x2), a);
   fe x6 = fe_mul(fe_sqr_n(x3, 3), x3);
@@ -314,6 +314,170 @@ __host__ __device__ __noinline__ inline fe fe_inv(const fe& a) {
   t = fe_mul(fe_sqr_n(t, 5), a);
   t = fe_mul(fe_sqr_n(t, 3), x2);
   return fe_mul(fe_sqr_n(t, 2), a);
+}
+
+// ---- the same inverse without the 255 squarings (round 4): Bernstein-Yang division steps ("safegcd", eprint 2019/266) ----------------
+// fe_modp_inv's value (lib/ecc.c:463-520) by another algorithm: a GCD-style iteration on (f, g) = (p, a) whose every step looks at
+// one bit of g, so 30 steps at a time run on the low words alone and are applied to the full-width values as one 2 x 2 matrix.
+//   divstep (half-delta form, zeta = -(delta + 1/2), starts at -1):
+//     g odd and zeta < 0:  (zeta, f, g) <- (-zeta - 2, g, (g - f) / 2)
+//     otherwise:           (zeta, f, g) <- (zeta - 1,  f, (g + (g odd ? f : 0)) / 2)
+//   590 steps bring g to 0 for any 256-bit input (the published bound for this form); 20 rounds x 30 = 600 are done, every lane
+//   the same number: no divergence, no data-dependent branch.  d, e follow along with d a = f, e a = g (mod p), kept in (-2p, p);
+//   at the end f = +-1 and the inverse is +-d.
+// Cost on gfx950: ~720 one-clock-class VALU ops (and / xor / add / shift) per round for the steps + ~200 (72 v_mad_i64_i32) for
+// the two matrix applications = ~18 500 instructions against ~34 200 (of which 23 000 v_mad_u64_u32) for the addition chain.
+// Working form: 9 signed limbs of 30 bits (the matrix entries are <= 2^30 in magnitude: products and their sums fit 64 bits).
+typedef int32_t i32;
+typedef int64_t i64;
+struct ds30 {
+  i32 v[9];  // value = sum v[i] 2^(30 i); v[0..7] in [0, 2^30) between rounds, v[8] carries the sign
+};
+struct ds_mat {
+  i32 u, v, q, r;  // 2^30 (f', g') = (u f + v g, q f + r g)
+};
+#define DS_M30 0x3FFFFFFF
+#define DS_PINV30 0x2DDACACFu /* p^-1 mod 2^30 */
+// 30 division steps on the low words; returns the new zeta.  The matrix rows follow the row operations of (f, g): (u, v) with f,
+// (q, r) with g, doubled instead of halved.  Ten steps at a time both entries of a row share one register (u + v 2^16: every
+// operation of a step is linear, and |u| + |v| <= 2^10 leaves the fields apart), the three 10-step matrices are multiplied out in
+// 32 bits: 17 instructions per step + 42 per round instead of 24 per step.
+#ifndef ECL_DS_PACKED
+#define ECL_DS_PACKED 1 /* A/B: 0 = the four matrix entries in registers of their own, 30 steps in one go */
+#endif
+FE_FN i32 ds_divsteps30(i32 zeta, u32 f, u32 g, ds_mat& t) {
+#if ECL_DS_PACKED
+  i32 mu = 1, mv = 0, mq = 0, mr = 1;  // matrix of the steps done so far in this round
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    u32 uv = 1u, qr = 1u << 16;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      u32 c1 = (u32)(zeta >> 31);    // all ones: zeta < 0
+      const u32 c2 = 0u - (g & 1u);  // all ones: g odd
+      const u32 x = (f ^ c1) - c1, y = (uv ^ c1) - c1;  // -f, -(u, v) where zeta < 0
+      g += x & c2, qr += y & c2;
+      c1 &= c2;                      // swap
+      zeta = (i32)((u32)zeta ^ c1) - 1;
+      f += g & c1, uv += qr & c1;
+      g >>= 1, uv <<= 1;
+    }
+    const i32 u = (i32)(uv << 16) >> 16, v = (i32)(uv - (u32)u) >> 16;
+    const i32 q = (i32)(qr << 16) >> 16, r = (i32)(qr - (u32)q) >> 16;
+    if (part == 0) mu = u, mv = v, mq = q, mr = r;
+    else {
+      const i32 nu = u * mu + v * mq, nv = u * mv + v * mr, nq = q * mu + r * mq, nr = q * mv + r * mr;
+      mu = nu, mv = nv, mq = nq, mr = nr;
+    }
+  }
+  t.u = mu, t.v = mv, t.q = mq, t.r = mr;
+  return zeta;
+#else
+  u32 u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+  for (int i = 0; i < 30; ++i) {
+    u32 c1 = (u32)(zeta >> 31);    // all ones: zeta < 0
+    const u32 c2 = 0u - (g & 1u);  // all ones: g odd
+    const u32 x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;  // -f, -u, -v where zeta < 0
+    g += x & c2, q += y & c2, r += z & c2;
+    c1 &= c2;                      // swap
+    zeta = (i32)((u32)zeta ^ c1) - 1;
+    f += g & c1, u += q & c1, v += r & c1;
+    g >>= 1, u <<= 1, v <<= 1;
+  }
+  t.u = (i32)u, t.v = (i32)v, t.q = (i32)q, t.r = (i32)r;
+  return zeta;
+#endif
+}
+// (f, g) <- t (f, g) / 2^30 (exact)
+FE_FN void ds_update_fg(ds30& f, ds30& g, const ds_mat& t) {
+  i64 cf = (i64)t.u * f.v[0] + (i64)t.v * g.v[0];
+  i64 cg = (i64)t.q * f.v[0] + (i64)t.r * g.v[0];
+  cf >>= 30, cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cf += (i64)t.u * f.v[i] + (i64)t.v * g.v[i];
+    cg += (i64)t.q * f.v[i] + (i64)t.r * g.v[i];
+    f.v[i - 1] = (i32)cf & DS_M30, g.v[i - 1] = (i32)cg & DS_M30;
+    FE_HIDE24(f.v[i - 1]);
+    FE_HIDE24(g.v[i - 1]);  // known non-negative, the products become unsigned x signed: three instructions instead of one v_mad_i64_i32
+    cf >>= 30, cg >>= 30;
+  }
+  f.v[8] = (i32)cf, g.v[8] = (i32)cg;
+}
+// (d, e) <- t (d, e) / 2^30 (mod p): a multiple of p = 2^256 - 2^32 - 977 (signed limbs -977, -4, 0, ..., 0, 2^16) makes each sum
+// divisible; negative d / e are taken as d + p, e + p first, which keeps the results in (-2p, p)
+FE_FN void ds_update_de(ds30& d, ds30& e, const ds_mat& t) {
+  const i32 sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  i32 md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+  i64 cd = (i64)t.u * d.v[0] + (i64)t.v * e.v[0];
+  i64 ce = (i64)t.q * d.v[0] + (i64)t.r * e.v[0];
+  md -= (i32)((DS_PINV30 * (u32)cd + (u32)md) & DS_M30);
+  me -= (i32)((DS_PINV30 * (u32)ce + (u32)me) & DS_M30);
+  cd -= (i64)md * 977, ce -= (i64)me * 977;
+  cd >>= 30, ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cd += (i64)t.u * d.v[i] + (i64)t.v * e.v[i];
+    ce += (i64)t.q * d.v[i] + (i64)t.r * e.v[i];
+    if (i == 1) cd -= (i64)md * 4, ce -= (i64)me * 4;
+    if (i == 8) cd += (i64)md * 65536, ce += (i64)me * 65536;
+    d.v[i - 1] = (i32)cd & DS_M30, e.v[i - 1] = (i32)ce & DS_M30;
+    FE_HIDE24(d.v[i - 1]);
+    FE_HIDE24(e.v[i - 1]);
+    cd >>= 30, ce >>= 30;
+  }
+  d.v[8] = (i32)cd, e.v[8] = (i32)ce;
+}
+// any magnitude <= 7 in, canonical residue out; 0 -> 0 like the addition chain
+__host__ __device__ __noinline__ inline fe fe_inv_divsteps(fe a) {
+  fe_normalize(a);
+  ds30 f, g, d, e;
+  f.v[0] = 0x3FFFFC2F, f.v[1] = 0x3FFFFFFB, f.v[8] = 0xFFFF;
+#pragma unroll
+  for (int i = 2; i < 8; ++i) f.v[i] = DS_M30;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g.v[i] = (i32)((a.n[i] >> i | a.n[i + 1] << (29 - i)) & DS_M30);
+  g.v[8] = (i32)(a.n[8] >> 8);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d.v[i] = 0, e.v[i] = 0;
+  e.v[0] = 1;
+  i32 zeta = -1;
+#pragma unroll 1
+  for (int round = 0; round < 20; ++round) {
+    ds_mat t;
+    zeta = ds_divsteps30(zeta, (u32)f.v[0], (u32)g.v[0], t);
+    ds_update_de(d, e, t);
+    ds_update_fg(f, g, t);
+  }
+  // g = 0, f = +-1 (f = p, d = 0 if a was 0): the inverse is d * sign(f), brought from (-2p, p) to [0, p)
+  const i32 neg = f.v[8] >> 31;
+  i32 m = d.v[8] >> 31;
+  d.v[0] += -977 & m, d.v[1] += -4 & m, d.v[8] += 65536 & m;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d.v[i] = (d.v[i] ^ neg) - neg;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d.v[i + 1] += d.v[i] >> 30, d.v[i] &= DS_M30;
+  m = d.v[8] >> 31;
+  d.v[0] += -977 & m, d.v[1] += -4 & m, d.v[8] += 65536 & m;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d.v[i + 1] += d.v[i] >> 30, d.v[i] &= DS_M30;
+  fe r;
+  r.n[0] = (u32)d.v[0] & FE_M;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) r.n[i] = ((u32)d.v[i - 1] >> (30 - i) | (u32)d.v[i] << i) & FE_M;
+  FE_HIDE24(r.n[8]);
+  return r;
+}
+#ifndef ECL_FE_INV_DIVSTEPS
+#define ECL_FE_INV_DIVSTEPS 1 /* A/B: 0 = the addition chain everywhere */
+#endif
+FE_FN fe fe_inv(const fe& a) {
+#if ECL_FE_INV_DIVSTEPS
+  return fe_inv_divsteps(a);
+#else
+  return fe_inv_fermat(a);
+#endif
 }
 
 // secp256k1 constants as canonical little-endian u32 words

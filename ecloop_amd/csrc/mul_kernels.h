@@ -147,6 +147,40 @@ __device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
   }
   return acc;
 }
+#ifndef ECL_MUL_XYZZ
+#define ECL_MUL_XYZZ 1  /* A/B: 0 = Jacobian window sums (8M + 3S per table point, round 4's first form) */
+#endif
+// ... and with Z^2, Z^3 carried instead of Z (ec.h: xyzz_madd_lazy, 8M + 2S per table point).  Same states; a single point returns
+// with ZZ = ZZZ = 1.
+__device__ __forceinline__ xyzz wtab_sum_xyzz(const u32 kk[9], const wtab t) {
+  xyzz acc;
+  acc.X = fe_zero(), acc.Y = fe_zero(), acc.ZZ = fe_one(), acc.ZZZ = fe_one(), acc.inf = 1;
+  u32 npts = 0;
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  u32 dnext = wtab_digit(kk, t, 0);
+  if (dnext) {
+    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
+#pragma unroll 1
+  for (u32 w = 0; w < t.nwin; ++w) {
+    const u32 digit = dnext;
+    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    if (dnext) {
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+    }
+    if (!digit) continue;
+    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+    const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
+    if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
+    else if (npts == 1) acc = xyzz_mmadd_lazy(acc.X, acc.Y, qx, qy);
+    else acc = xyzz_madd_lazy(acc, qx, qy);
+    ++npts;
+  }
+  return acc;
+}
 // rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
 // consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
 __global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
@@ -227,6 +261,49 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
   if (t >= nt) return;
   fe prod = fe_one();
   u32 infmask = 0;
+#if ECL_MUL_XYZZ
+  // parked per scalar: X * ZZZ, Y * ZZ, T = ZZ * ZZZ and the running product of the T's; x = X ZZZ / T, y = Y ZZ / T
+#pragma unroll 1
+  for (u32 r = 0; r < R; ++r) {
+    const u32 i = r * nt + t;
+    if (i >= n) break;
+    u32 kk[9];
+    const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
+    kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
+    xyzz acc = wtab_sum_xyzz(kk, gtab);
+    // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves ZZ = 0, and a zero in
+    // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
+    if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
+    infmask |= (acc.inf ? 1u : 0u) << r;
+    const fe tt = acc.inf ? fe_one() : fe_mul(acc.ZZ, acc.ZZZ);
+    const fe xs = fe_mul(acc.X, acc.ZZZ), ys = fe_mul(acc.Y, acc.ZZ);
+    u32* p = tmp + (size_t)r * 36 * nt + t;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      p[(size_t)l * nt] = xs.n[l], p[(size_t)(9 + l) * nt] = ys.n[l];
+      p[(size_t)(18 + l) * nt] = tt.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+    }
+    prod = fe_mul(prod, tt);
+  }
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = R; r-- > 0;) {
+    const u32 i = r * nt + t;
+    if (i >= n) continue;
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, T, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      T.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe ti = fe_mul(inv, pre);
+    inv = fe_mul(inv, T);
+    if ((infmask >> r) & 1u) continue;
+    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
+    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
+  }
+#else
 #pragma unroll 1
   for (u32 r = 0; r < R; ++r) {
     const u32 i = r * nt + t;
@@ -267,6 +344,7 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     const fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
     check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
   }
+#endif
 }
 // `mul -raw` (main.c:505-527): the scalar of a line is the SHA-256 of its bytes.  One lane per line: the line's bytes are
 // gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and

@@ -38,6 +38,9 @@ void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
     break;
   }
   case 9: z = fe_mul(fe_neg(fe_add(x, x), 2), fe_add(y, y)); break;  // magnitudes 3 x 2 with a negated operand
+  case 10: z = fe_inv_divsteps(x); break;
+  case 11: z = fe_inv_fermat(x); break;
+  case 12: z = fe_inv_divsteps(fe_add(fe_neg(fe_add(x, x), 2), fe_add(fe_add(y, y), fe_add(y, y)))); break;  // 1 / (4y - 2x), magnitude 7 in
   default: z = fe_zero();
   }
   st(r, z);
@@ -56,6 +59,20 @@ int dh_mulg(uint64_t x[4], uint64_t y[4], const uint64_t k[4]) {
   int ok = ec_mul_g_affine(ax, ay, kw);
   st(x, ax), st(y, ay);
   return ok;
+}
+// sum of n >= 1 affine points (x[i], y[i]) by the lazy XYZZ additions of `mul` (affine + affine first, then mixed), made affine the way
+// k_mul_check does it (X ZZZ / T, Y ZZ / T with T = ZZ ZZZ); returns 0 when the chain degenerated (ZZ = 0)
+int dh_xyzz_sum(uint64_t x[4], uint64_t y[4], const uint64_t* px, const uint64_t* py, int n) {
+  xyzz acc;
+  acc.X = ld(px), acc.Y = ld(py), acc.ZZ = fe_one(), acc.ZZZ = fe_one(), acc.inf = 0;
+  for (int i = 1; i < n; ++i) {
+    const fe qx = ld(px + 4 * i), qy = ld(py + 4 * i);
+    acc = i == 1 ? xyzz_mmadd_lazy(acc.X, acc.Y, qx, qy) : xyzz_madd_lazy(acc, qx, qy);
+  }
+  if (fe_is_zero(acc.ZZ)) return 0;
+  const fe ti = fe_inv(fe_mul(acc.ZZ, acc.ZZZ));
+  st(x, fe_mul(fe_mul(acc.X, acc.ZZZ), ti)), st(y, fe_mul(fe_mul(acc.Y, acc.ZZ), ti));
+  return 1;
 }
 int dh_parity(const uint64_t a[4], const uint64_t b[4]) { return (int)fe_parity(fe_sub(fe_add(ld(a), ld(a)), ld(b))); }
 int dh_bloom_has(const uint64_t* bits, uint64_t nwords, const uint32_t h[5]) {

@@ -195,8 +195,9 @@ const char *ecl_hip_strerror(int code);
 const char *ecl_hip_last_error(const ecl_hip *h);
 
 /* ---- diagnostics: device primitives exposed for parity tests (each runs a tiny kernel) ---- */
-/* op: 0 mul, 1 sqr, 2 inv, 3 sub, 4 add, 5 neg, 6 sqr(sqr a), 7 (a*b)*b, 8 sqr(a)*a; a,b,r: n field elements as 4
-   little-endian u64 limbs */
+/* op: 0 mul, 1 sqr, 2 inv (the one the kernels use), 3 sub, 4 add, 5 neg, 6 sqr(sqr a), 7 (a*b)*b, 8 sqr(a)*a, 9 inv by division steps,
+   10 inv by the addition chain of lib/ecc.c:463-520, 11 1 / (4b - 2a) by division steps from an unnormalised operand; a,b,r: n field
+   elements as 4 little-endian u64 limbs */
 int ecl_hip_diag_fe(ecl_hip *h, int op, const uint64_t (*a)[4], const uint64_t (*b)[4], uint64_t (*r)[4], uint32_t n);
 /* affine public keys of n scalars (double-and-add kernel); ok[i] = 0 for the point at infinity */
 int ecl_hip_diag_mulg(ecl_hip *h, const uint64_t (*k)[4], uint64_t (*x)[4], uint64_t (*y)[4], uint8_t *ok, uint32_t n);

@@ -51,6 +51,32 @@ def test_field(D):
         assert op(2, a) == pow(a, P - 2, P)
 
 
+def test_inverse_by_division_steps_equals_the_addition_chain(D):
+    """fe_inv_divsteps (600 Bernstein-Yang division steps in 20 rounds of 30) against pow(a, p - 2, p) and against the 255 S + 15 M
+    chain of lib/ecc.c:463-520, on edge values (0, +-1, powers of two, values around the limb boundaries, inputs whose low words
+    are all zeros / all ones so that whole rounds are pure halvings) and random ones; unnormalised input of magnitude 7."""
+    rnd = random.Random(5)
+    P = orc.P
+
+    def op(o, a, b=0):
+        r = orc.FE()
+        D.dh_fe_op(o, r, orc.fe(a), orc.fe(b))
+        return orc.val(r)
+
+    edge = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, 0x1000003D1, P - 0x1000003D1, 1 << 255, (1 << 255) - 1, 1 << 30, 1 << 60, 1 << 240, (1 << 30) - 1,
+            (1 << 240) + 1, ((1 << 256) - 1) % P, (1 << 232) - 1, P - (1 << 29), 0x3FFFFFFF << 30, 1 << 29, 1 << 58, 3 << 90, (1 << 200) - (1 << 100)]
+    edge += [pow(2, -k, P) for k in (1, 30, 31, 60, 300, 590, 600)] + [pow(3, k, P) for k in (100, 200, 255)]
+    vals = edge + [rnd.randrange(P) for _ in range(3000)]
+    for a in vals:
+        want = pow(a, P - 2, P)
+        assert op(10, a) == want, hex(a)
+    for a in vals[:200]:
+        assert op(11, a) == pow(a, P - 2, P)
+    for a in vals[:300]:
+        b = rnd.randrange(P)
+        assert op(12, a, b) == pow((4 * b - 2 * a) % P, P - 2, P)
+
+
 def test_scalar_mul_and_hash160(D):
     rnd = random.Random(4)
     for k in [1, 2, 3, 5, 0xDC2A04, orc.N - 1, (orc.N + 1) // 2, 1 << 255] + [rnd.randrange(1, orc.N) for _ in range(12)]:
@@ -63,6 +89,29 @@ def test_scalar_mul_and_hash160(D):
         assert list(h65) == orc.hash160(orc.val(x), orc.val(y), False)
     x, y = orc.FE(), orc.FE()
     assert D.dh_mulg(x, y, orc.fe(0)) == 0 and D.dh_mulg(x, y, orc.fe(orc.N)) == 0
+
+
+def test_xyzz_lazy_sums_equal_the_scalar_sum(D):
+    """`mul`'s window sums (ec.h: xyzz_mmadd_lazy / xyzz_madd_lazy, lazy magnitudes, no exceptional cases) against the
+    oracle's k*G for the sum of the scalars; P = Q / P = -Q on the way must leave ZZ = 0 (the kernel's one test per scalar)."""
+    rnd = random.Random(11)
+    for n in [1, 2, 3, 5, 12, 13, 19]:
+        for _ in range(4):
+            ks = [rnd.randrange(1, orc.N) for _ in range(n)]
+            pts = [orc.point_of(k) for k in ks]
+            px = (C.c_uint64 * (4 * n))(*[w for p in pts for w in orc.fe(p[0])])
+            py = (C.c_uint64 * (4 * n))(*[w for p in pts for w in orc.fe(p[1])])
+            x, y = orc.FE(), orc.FE()
+            assert D.dh_xyzz_sum(x, y, px, py, n) == 1
+            assert (orc.val(x), orc.val(y)) == orc.point_of(sum(ks) % orc.N)
+    for ks in [[5, 5], [5, orc.N - 5], [3, 4, 7, 9], [3, 4, orc.N - 7, 9], [2, 3, 4, 9, 11]]:
+        n = len(ks)
+        pts = [orc.point_of(k) for k in ks]
+        px = (C.c_uint64 * (4 * n))(*[w for p in pts for w in orc.fe(p[0])])
+        py = (C.c_uint64 * (4 * n))(*[w for p in pts for w in orc.fe(p[1])])
+        x, y = orc.FE(), orc.FE()
+        degenerate = any(sum(ks[:i]) % orc.N in (ks[i], orc.N - ks[i]) for i in range(1, n))
+        assert D.dh_xyzz_sum(x, y, px, py, n) == (0 if degenerate else 1)
 
 
 @pytest.mark.parametrize("nw,mode", [(12345, "a|(b&c)"), (1, "ones"), (2, "a|b"), (4099, "a|b"), (1 << 16, "a|b")])

@@ -39,6 +39,23 @@ def test_field_ops(dev):
     assert dev.diag_fe(2, nz) == [pow(x, P - 2, P) for x in nz]
 
 
+def test_inverse_by_division_steps_and_by_the_addition_chain(dev):
+    """fe_inv_divsteps (what fe_inv is since round 4: 600 division steps) and fe_inv_fermat (lib/ecc.c:463-520) on the device against
+    pow(a, p - 2, p): edge values (0 included: both give 0), inputs that make whole rounds pure halvings or pure swaps, 20 000
+    random values; unnormalised input of magnitude 7."""
+    rnd = random.Random(13)
+    P = orc.P
+    edge = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, 0x1000003D1, P - 0x1000003D1, 1 << 255, (1 << 255) - 1, 1 << 30, 1 << 60, 1 << 240, (1 << 30) - 1,
+            (1 << 240) + 1, ((1 << 256) - 1) % P, (1 << 232) - 1, P - (1 << 29), 0x3FFFFFFF << 30, 1 << 29, 1 << 58, 3 << 90, (1 << 200) - (1 << 100)]
+    edge += [pow(2, -k, P) for k in (1, 30, 31, 60, 300, 590, 600)] + [pow(3, k, P) for k in (100, 200, 255)]
+    a = edge + [rnd.randrange(P) for _ in range(20000)]
+    want = [pow(x, P - 2, P) for x in a]
+    assert dev.diag_fe(9, a) == want
+    assert dev.diag_fe(10, a[:4000]) == want[:4000]
+    b = [rnd.randrange(P) for _ in a[:4000]]
+    assert dev.diag_fe(11, a[:4000], b) == [pow((4 * y - 2 * x) % P, P - 2, P) for x, y in zip(a, b)]
+
+
 def test_scalar_mul_and_hash160(dev):
     rnd = random.Random(12)
     ks = [1, 2, 3, 0xDC2A04, orc.N - 1, (orc.N + 1) // 2, 1 << 255, 0, orc.N] + [rnd.randrange(1, orc.N) for _ in range(120)]
