@@ -28,6 +28,10 @@ static int ensure_gtable(ecl_hip* h) {
 // device that uses the width (the host program runs two per GPU), freed with the last of them.  Before a table is handed
 // out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
 // are compared with the double-and-add kernel.
+#ifndef ECL_MUL_SPLIT
+#define ECL_MUL_SPLIT 0  /* 1: k_mul_sum + k_mul_finish instead of k_mul_check (measured equal: profiles/r04_mul_split.txt) */
+#endif
+#define MUL_CMAX 4u  /* at most this many chains per summing thread (two-kernel form) */
 #define MUL_W_MIN 8u
 #define MUL_W_MAX 26u  /* 10 rows x 2^26 points: 43 GB */
 #define MUL_W_START 20u               /* 13 rows x 2^20 points, 809 MB: first call 48 ms against 41 ms at 14 bits and 47 at 18 */
@@ -178,8 +182,9 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
     h->d_multmp = nullptr, h->kbuf_cap = 0;
     for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
     // the kernel indexes the planes as r * 36 * nt + plane * nt + t with nt = ceil(m / R) rounded up to whole workgroups:
-    // up to R * 256 slots more than m
-    HIPCHK(h, hipMalloc(&h->d_multmp, ((size_t)want + MUL_R * 256u) * 36 * sizeof(u32)));
+    // up to R * 256 * C slots more than m (C <= MUL_CMAX chains per summing thread)
+    // (+ 10 words per thread behind the planes: the chain products and infinity masks that k_mul_sum hands to k_mul_finish)
+    HIPCHK(h, hipMalloc(&h->d_multmp, (((size_t)want + MUL_R * 256u * MUL_CMAX) * 36 + ((size_t)want + 256u * MUL_CMAX) * 10) * sizeof(u32)));
     h->kbuf_cap = want;
   }
   return ECL_OK;
@@ -187,11 +192,50 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
 // threads and scalars per thread of one k_mul_check launch over m scalars: as many scalars per thread (one shared inversion, at most
 // MUL_R) as still keep 65536 x ECL_MUL_WAVES threads in flight - what the chip holds at once; a few blocks more would wait for a whole
 // round - in whole workgroups, so that every row of scalars and every parking plane starts on a 1 KiB boundary
-static void mul_geometry(u32 m, u32* R_out, u32* nt_out) {
-  static const u32 nt_target = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 65536u * ECL_MUL_WAVES;  // tuning hook (A/B runs)
-  u32 R = (m + nt_target - 1) / nt_target;
+static u32 mul_nt_target() {
+  static const u32 v = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 65536u * (ECL_MUL_SPLIT ? ECL_MUL_SUM_WAVES : ECL_MUL_WAVES);  // tuning hook (A/B runs)
+  return v;
+}
+// chains per summing thread (two-kernel form): the finishing kernel (hash-bound, 120 VGPRs) may hold more waves per SIMD than the summing
+// kernel; a piece is then cut into as many chains as the finishing kernel has lanes and the summing threads take several each
+static u32 mul_chains_per_thread() {
+#if ECL_MUL_SPLIT
+  static_assert(ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES >= 1 && ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES <= (int)MUL_CMAX, "chains per summing thread");
+  static const u32 C = getenv("ECL_HIP_MUL_CHAINS") && atoi(getenv("ECL_HIP_MUL_CHAINS")) >= 1 && atoi(getenv("ECL_HIP_MUL_CHAINS")) <= (int)MUL_CMAX
+                           ? (u32)atoi(getenv("ECL_HIP_MUL_CHAINS")) : (u32)(ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES);
+  return C;
+#else
+  return 1u;
+#endif
+}
+static void mul_geometry(u32 m, u32 C, u32* R_out, u32* nt_out) {
+  const u32 chains = mul_nt_target() * C;
+  u32 R = (m + chains - 1) / chains;
   R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
-  *R_out = R, *nt_out = ((m + R - 1) / R + 255u) & ~255u;
+  const u32 unit = 256u * C;
+  *R_out = R, *nt_out = ((m + R - 1) / R + unit - 1u) / unit * unit;
+}
+// one piece: the window sums, then inversion + hashing (two kernels: ECL_MUL_SPLIT) or all of it in k_mul_check
+static void mul_launch_piece(ecl_hip* h, const u32* d_k, u32 m, u32 at, const wtab& gtab, const add_args& a) {
+  u32 R, nt;
+  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
+#if ECL_MUL_SPLIT
+  const u32 C = mul_chains_per_thread();
+  mul_geometry(m, C, &R, &nt);
+  u32* chain = h->d_multmp + ((size_t)h->kbuf_cap + MUL_R * 256u * MUL_CMAX) * 36;
+  dim3 blk(256);
+  hipLaunchKernelGGL(k_mul_sum, dim3((nt / C + 255u) / 256u), blk, 0, h->stream, d_k, m, gtab, h->d_multmp, chain, nt, R, C);
+  dim3 grid(nt / 256);
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_finish<true, true>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
+  else if (a33) hipLaunchKernelGGL((k_mul_finish<true, false>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
+  else hipLaunchKernelGGL((k_mul_finish<false, true>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
+#else
+  mul_geometry(m, 1, &R, &nt);
+  dim3 grid(nt / 256), blk(256);
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
+#endif
 }
 // window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
 static u32 mul_window_for(const ecl_hip* h, u32 n) {
@@ -259,7 +303,6 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
   a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
-  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
   // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel: a first piece of 2^18 scalars (nothing
@@ -271,12 +314,14 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   // staging buffers the copy of piece c + 1 starts when the kernel of piece c - 1 ends, and a piece twice as long as the last does
   // not arrive in time.  Fewer than 2^17 threads per kernel cost more than they save; 196 608 or 262 144 threads do too (829 / 1075
   // against 1097 M scalars/s).
-  static const u32 first_log2 = getenv("ECL_HIP_MUL_FIRST") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST")) : 18u;   // tuning hooks (A/B runs)
+  // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
+  static const u32 first_R = getenv("ECL_HIP_MUL_FIRST_R") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST_R")) : 2u;   // tuning hooks (A/B runs)
   static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 1600u;
-  static const u32 top_fixed = getenv("ECL_HIP_MUL_TOP") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP")) : 0u;
-  const u32 top_log2 = top_fixed ? top_fixed : (n >= (1u << 25) ? 21u : 20u);
-  const u32 top = h->kbuf_cap < (1u << top_log2) ? h->kbuf_cap : 1u << top_log2;
-  u32 lim = top < (1u << first_log2) ? top : 1u << first_log2;
+  static const u32 top_R = getenv("ECL_HIP_MUL_TOP_R") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP_R")) : 0u;
+  const u64 unit = (u64)mul_nt_target() * mul_chains_per_thread();
+  const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 25) ? 16u : 8u));
+  const u32 top = h->kbuf_cap < top_want ? h->kbuf_cap : (u32)top_want;
+  u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
     const u32 b = c & 1;
@@ -287,12 +332,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-    u32 R, nt;
-    mul_geometry(m, &R, &nt);
-    dim3 grid(nt / 256), blk(256);
-    if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
-    else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
-    else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[b], m, at, gtab, a, h->d_multmp, nt, R);
+    mul_launch_piece(h, h->d_kbuf[b], m, at, gtab, a);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
   }
@@ -360,13 +400,7 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
   hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
-  u32 R, nt;
-  mul_geometry(n, &R, &nt);
-  dim3 grid(nt / 256), blk(256);
-  const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
-  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
-  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
-  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, h->d_kbuf[0], n, 0u, gtab, a, h->d_multmp, nt, R);
+  mul_launch_piece(h, h->d_kbuf[0], n, 0u, gtab, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;

@@ -346,6 +346,155 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
   }
 #endif
 }
+// ---- the summing kernel's own form of the window sum (round 4): written for a small register budget (three waves per SIMD) --------
+// * the scalar stays in memory: a digit is one 8-byte load at the digit's word (L2 / L1 hits after the first window: a wave's scalars
+//   are 2 KiB of contiguous memory) + a shift, not a 16-way select over eight registers, and is fetched one window ahead;
+// * a table point's 16 words are requested after the two multiplications that consume the previous point (u2 = qx ZZ, s2 = qy ZZZ),
+//   so the 18 limbs of one point and the 16 words of the next are never live together;
+// * no per-lane control flow: windows 0 and 1 are added as affine + affine, every later one by the mixed addition; a zero digit
+//   (2^-22 per window for a random scalar; small test scalars have many) takes slot 0 of its row instead and flags the scalar, which the
+//   caller then sends through the complete sum (wtab_sum_complete) like one whose chain degenerated (ZZ = 0).
+__device__ __forceinline__ u32 wtab_digit_mem(const u32* __restrict__ kw, const wtab& t, u32 w) {
+  u32 bit = w * t.W, word = bit >> 5, sh = bit & 31u;
+  if (word > 6u) word = 6u, sh += 32u;  // the last words: shift further instead of reading past the scalar
+  const u64 v = *(const u64*)(kw + word);  // 4-byte aligned 8-byte load
+  return (u32)(v >> sh) & t.per;
+}
+__device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad) {
+  u32 d0 = wtab_digit_mem(kw, t, 0), d1 = wtab_digit_mem(kw, t, 1), dn = t.nwin > 2u ? wtab_digit_mem(kw, t, 2) : 1u;
+  bad = (d0 == 0u) | (d1 == 0u);
+  d0 = d0 ? d0 : 1u, d1 = d1 ? d1 : 1u;
+  xyzz acc;
+  {
+    const uint4* e0 = (const uint4*)(t.p + ((size_t)d0 - 1) * 16);
+    const uint4* e1 = (const uint4*)(t.p + ((size_t)t.per + d1 - 1) * 16);
+    const uint4 a0 = e0[0], a1 = e0[1], a2 = e0[2], a3 = e0[3], b0 = e1[0], b1 = e1[1], b2 = e1[2], b3 = e1[3];
+    const u32 pxw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pyw[8] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+    const u32 qxw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, qyw[8] = {b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_from_words(pyw), fe_from_words(qxw), fe_from_words(qyw));
+  }
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+  if (t.nwin > 2u) {
+    bad |= dn == 0u;
+    dn = dn ? dn : 1u;
+    const uint4* e = (const uint4*)(t.p + ((size_t)2 * t.per + dn - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+  }
+#pragma unroll 1
+  for (u32 w = 2; w < t.nwin; ++w) {
+    const u32 xw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w}, yw[8] = {n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+    const bool more = w + 1u < t.nwin;
+    dn = more ? wtab_digit_mem(kw, t, w + 1u) : 1u;
+    const fe u2 = fe_mul(fe_from_words(xw), acc.ZZ), s2 = fe_mul(fe_from_words(yw), acc.ZZZ);
+    if (more) {
+      bad |= dn == 0u;
+      dn = dn ? dn : 1u;
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1u) * t.per + dn - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
+    }
+    fe h = fe_sub(u2, acc.X);
+    fe_normalize_weak(h);
+    fe rr = fe_add(s2, fe_neg(acc.Y, 3));
+    fe_normalize_weak(rr);
+    const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(acc.X, hh);
+    fe X3 = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
+    fe_normalize_weak(X3);
+    acc.Y = fe_add(fe_mul(rr, fe_sub(v, X3)), fe_neg(fe_mul(acc.Y, hhh), 1));
+    acc.X = X3;
+    acc.ZZ = fe_mul(acc.ZZ, hh);
+    acc.ZZZ = fe_mul(acc.ZZZ, hhh);
+  }
+  return acc;
+}
+// The same work as two kernels (round 4, ECL_MUL_SPLIT): k_mul_sum = the window sums and the parking, no hashing in its code or in its
+// register budget; k_mul_finish = one inversion per thread, the walk back, hash160 + probe.  Same threads, same chains, same parking
+// space (+ the chain products and infinity masks of a piece: 40 bytes per thread); the pieces of a call alternate on the stream.
+#ifndef ECL_MUL_SUM_WAVES
+#define ECL_MUL_SUM_WAVES 2
+#endif
+#ifndef ECL_MUL_SUM_FAST
+#define ECL_MUL_SUM_FAST 1 /* A/B: 0 = wtab_sum_xyzz (scalar in registers, per-lane states) in the summing kernel */
+#endif
+#ifndef ECL_MUL_FIN_WAVES
+#define ECL_MUL_FIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, ECL_MUL_SUM_WAVES) k_mul_sum(const u32* __restrict__ k, u32 n, const wtab gtab, u32* __restrict__ tmp,
+                                                                     u32* __restrict__ chain, u32 nt, u32 R, u32 C) {
+  // nt chains of R scalars each (chain c: scalars c, c + nt, ...), C chains per thread (c = t, t + nt / C, ...): the finishing kernel runs
+  // one thread per chain at twice this kernel's occupancy
+  const u32 t = blockIdx.x * 256u + threadIdx.x, nts = nt / C;
+  if (t >= nts) return;
+#pragma unroll 1
+  for (u32 c = t; c < nt; c += nts) {
+    fe prod = fe_one();
+    u32 infmask = 0;
+#pragma unroll 1
+    for (u32 r = 0; r < R; ++r) {
+      const u32 i = r * nt + c;
+      if (i >= n) break;
+#if ECL_MUL_SUM_FAST
+      u32 bad;
+      xyzz acc = wtab_sum_fast(k + (size_t)i * 8, gtab, bad);
+      acc.inf = 0;
+      // a zero digit on the way (the sum took a stand-in point), or P = +-Q (h = 0 leaves ZZ = 0): the complete sum, out of line
+      if (__builtin_expect(bad || fe_is_zero(acc.ZZ), 0)) {
+        u32 kk[9];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk[j] = k[(size_t)i * 8 + j];
+        kk[8] = 0;
+        acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
+      }
+#else
+      u32 kk[9];
+      const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
+      kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
+      xyzz acc = wtab_sum_xyzz(kk, gtab);
+      if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
+#endif
+      infmask |= (acc.inf ? 1u : 0u) << r;
+      const fe tt = acc.inf ? fe_one() : fe_mul(acc.ZZ, acc.ZZZ);
+      const fe xs = fe_mul(acc.X, acc.ZZZ), ys = fe_mul(acc.Y, acc.ZZ);
+      u32* p = tmp + (size_t)r * 36 * nt + c;
+#pragma unroll
+      for (int l = 0; l < FE_LIMBS; ++l) {
+        p[(size_t)l * nt] = xs.n[l], p[(size_t)(9 + l) * nt] = ys.n[l];
+        p[(size_t)(18 + l) * nt] = tt.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
+      }
+      prod = fe_mul(prod, tt);
+    }
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) chain[(size_t)l * nt + c] = prod.n[l];
+    chain[(size_t)9 * nt + c] = infmask;
+  }
+}
+template <bool A33, bool A65>
+__global__ void __launch_bounds__(256, ECL_MUL_FIN_WAVES) k_mul_finish(u32 n, u32 base, add_args a, const u32* __restrict__ tmp,
+                                                                        const u32* __restrict__ chain, u32 nt, u32 R) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nt) return;
+  fe prod;
+#pragma unroll
+  for (int l = 0; l < FE_LIMBS; ++l) prod.n[l] = chain[(size_t)l * nt + t];
+  const u32 infmask = chain[(size_t)9 * nt + t];
+  fe inv = fe_inv(prod);
+#pragma unroll 1
+  for (u32 r = R; r-- > 0;) {
+    const u32 i = r * nt + t;
+    if (i >= n) continue;
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, T, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
+      T.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
+    }
+    const fe ti = fe_mul(inv, pre);
+    inv = fe_mul(inv, T);
+    if ((infmask >> r) & 1u) continue;
+    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
+    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
+  }
+}
 // `mul -raw` (main.c:505-527): the scalar of a line is the SHA-256 of its bytes.  One lane per line: the line's bytes are
 // gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and
 // compressed block by block; the digest, read as a big-endian 256-bit number, is written where k_mul_check expects the

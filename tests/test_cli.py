@@ -230,14 +230,15 @@ def test_rnd_window_is_an_add_over_the_printed_bounds(cli, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("size,mode,nwin", [(20, "ones", 1), (32, "a", 2)])
+@pytest.mark.parametrize("size,mode,nwin", [(20, "a|b", 1), (32, "a", 2)])
 def test_rnd_at_configs3_shape_against_the_oracle_on_the_printed_masks(cli, tmp_path, size, mode, nwin):
     """BASELINE configs[3]: `rnd -d 128:32` on a 168-bit range.  Every window the generator prints (two 64-digit masks,
     main.c:593-617) must hash exactly the keys the ORACLE's cmd_add workers hash on those bounds at stride 2^128 with
     cmd_rnd's full-size jobs (orc.add_range(..., offs=128, rnd=True): the restatement of main.c:405-454,619-662 that
-    tests/test_oracle_golden.py pins to the windows the reference itself drew).  All-ones filter (every key a hit) for the
-    2^21-key window; for the named config's real window size a half-dense synthetic filter (~4096 false positives per
-    2^32 keys): the oracle covers the first 2^30 and the last 2^28 keys of the first printed window and the first 2^28 keys of
+    tests/test_oracle_golden.py pins to the windows the reference itself drew).  A three-quarters-dense filter (~6600 hits) for the
+    2^21-key window, which the oracle covers whole (the all-ones filter of round 3 - two million found lines - spent three minutes in
+    this test's own line handling); for the named config's real window size a half-dense synthetic filter (~4096 false positives per
+    2^32 keys): the oracle covers the first 2^28 and the last 2^27 keys of the first printed window and the first 2^27 keys of
     the second (slices of the printed windows: the oracle runs at ~15 M keys/s on the box's host cores)."""
     import orc
     words = np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(70001, seed=23, mode=mode)
@@ -275,17 +276,17 @@ def test_rnd_at_configs3_shape_against_the_oracle_on_the_printed_masks(cli, tmp_
             covered += len(mine)
         else:
             # slices of the window through the oracle (its bounds are inclusive like -r; whole 2^21-key jobs): the first window's
-            # first 2^30 keys and last 2^28, the second window's first 2^28 - the oracle hashes ~15 M keys/s on the box's host
+            # first 2^28 keys and last 2^27, the second window's first 2^27 - the oracle hashes ~15 M keys/s on the box's host
             # cores (the whole 2^32-key window took 5 minutes when this test did that)
-            for first, count in ([(0, 1 << 30), (span - (1 << 28), 1 << 28)] if w == 0 else [(0, 1 << 28)]):
+            for first, count in ([(0, 1 << 28), (span - (1 << 27), 1 << 27)] if w == 0 else [(0, 1 << 27)]):
                 a = s + (first << 128)
                 rc, o, n, checked, hashed = orc.add_range(flt, a, a + ((count - 1) << 128), offs=128, rnd=True, threads=threads, cap=1 << 20)
                 assert rc == 0 and hashed == count
                 part = [l for l in mine if first <= key(l) < first + count]
-                assert part == sorted(orc.found_lines(o, n)) and len(part) > 100
+                assert part == sorted(orc.found_lines(o, n)) and len(part) > 60
                 covered += len(part)
             assert wins[w][4] == span and wins[w][3] == len(mine)
-    assert covered == (nwin << 21 if mode == "ones" else covered) and covered > 1000
+    assert covered > (3000 if size <= 21 else 300)
     assert "set-ups" in text
 
 
