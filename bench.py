@@ -299,8 +299,10 @@ class Ranks:
         self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         patience = datetime.timedelta(seconds=300)  # a rank that aborts (failed check) must not leave the others waiting for long
         if control == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
+            ndev = torch.cuda.device_count()
+            idx = local if local < ndev else local % max(ndev, 1)  # a launcher that shows each rank only its own GPU
+            torch.cuda.set_device(idx)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", idx), timeout=patience)
             self.tdev = "cuda"
         else:
             if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
@@ -380,6 +382,19 @@ def visible_gpus():
     return max(int(capi.load().ecl_hip_device_count()), 0)
 
 
+def device_identity(dev_index):
+    """what tells the GPUs of two ranks apart across processes: host + PCI address (+ uuid where the runtime reports one) of device
+    `dev_index` as this process sees it - the same enumeration the library's hipSetDevice uses"""
+    import socket
+    import torch
+    host = socket.gethostname()
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        return (host, getattr(p, "pci_domain_id", None), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None), str(getattr(p, "uuid", "")))
+    except Exception:  # no torch device behind the index (the CPU tests' stand-in device): the index is all there is
+        return (host, "index", dev_index)
+
+
 # ----------------------------------------------------------------------------------------------- mul (non-headline)
 
 
@@ -398,7 +413,7 @@ def bench_mul(args, sync, dev_index, emit):
             raise SystemExit("[bench] cannot pin the scalar array")
     out = np.zeros(64, dtype=np.dtype([("b", "u1", (32,))]))
     cnt = C.c_uint32()
-    # steady state of a long run: the 22-bit window table at once (left alone a context starts on 20 bits and moves to 22
+    # steady state of a long run: the 26-bit window table at once (left alone a context starts on 22 bits and moves to 26
     # after 2^30 scalars - more than this bench multiplies); `--mul-window 0` measures the automatic choice instead
     ks.dev.set_mul_window(args.mul_window)
     t_tab = time.perf_counter()
@@ -892,7 +907,7 @@ def main():
     ap.add_argument("--filter-n", type=int, default=FILTER_N, help="bloom entries (default 10^7 = 54 MB; 1.1e9 = 5.9 GB)")
     ap.add_argument("--cmd", default="add", choices=["add", "mul"], help="mul: the non-headline `mul` path")
     ap.add_argument("--mul-log2", type=int, default=24)
-    ap.add_argument("--mul-window", type=int, default=22, help="mul: window width of the table (0 = the library's automatic choice)")
+    ap.add_argument("--mul-window", type=int, default=26, help="mul: window width of the table (0 = the library's automatic choice)")
     ap.add_argument("--pageable", action="store_true", help="mul: scalars in pageable host memory (staged through pinned buffers by the library)")
     ap.add_argument("--no-secondary", action="store_true", help="N=1 headline run: skip the `secondary` legs (configs[2], [3], [4])")
     ap.add_argument("--cfg2-keys-log2", type=int, default=30)
@@ -946,11 +961,19 @@ def main():
     if launched and world > 1:
         sync = Ranks(args.control, local)  # rendezvous first: rank 0 has built the library by the time the others load it
         sync.barrier()
+        # one rank per PHYSICAL GPU.  A launcher may show every rank all GPUs (rank r takes device LOCAL_RANK) or only its own
+        # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank: device 0 of what the rank sees); what is refused is two ranks on the
+        # same device - told by host + PCI address, gathered over the rendezvous - never a line that says n_gpus=N for fewer GPUs
         have = visible_gpus()
-        if have < world and not share:
-            raise SystemExit(f"[bench] {world} ranks but {have} GPU(s) visible: refusing to report n_gpus={world} (one rank per GPU)")
+        if have < 1:
+            raise SystemExit(f"[bench] rank {sync.rank}: 0 GPU(s) visible")
+        dev = local if local < have else local % have
+        ids = sync.gather(device_identity(dev))
+        if len(set(ids)) < world and not share:
+            raise SystemExit(f"[bench] {world} ranks on {len(set(ids))} distinct GPU(s) ({have} GPU(s) visible to rank {sync.rank}): refusing to report "
+                             f"n_gpus={world} (one rank per GPU)")
         try:
-            work(sync, local % have if share else local)
+            work(sync, dev)
         finally:
             sync.close()
         return

@@ -33,11 +33,11 @@ static int ensure_gtable(ecl_hip* h) {
 #endif
 #define MUL_CMAX 4u  /* at most this many chains per summing thread (two-kernel form) */
 #define MUL_W_MIN 8u
-#define MUL_W_MAX 26u  /* 10 rows x 2^26 points: 43 GB */
-#define MUL_W_START 20u               /* 13 rows x 2^20 points, 809 MB: first call 48 ms against 41 ms at 14 bits and 47 at 18 */
-#define MUL_W_LONG 22u                /* 12 rows x 2^22 points, 3.0 GB: ~50 ms */
-#define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: at 955 vs 1006 M scalars/s the
-                                         wider table gains 0.05 ns per scalar, so its build is paid back after 10^9 of them */
+#define MUL_W_MAX 26u
+#define MUL_W_START 22u               /* 11 rows x 2^21 points (signed digits), 1.5 GB */
+#define MUL_W_LONG 26u                /* 9 rows x 2^25 points + 2^22, 19.6 GB: 10 additions per scalar instead of 12 */
+#define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: the wider table gains ~0.1 ns per scalar,
+                                         so its build is paid back after 10^9 of them */
 struct multab_t {
   u32* d = nullptr;
   int refs = 0;
@@ -73,7 +73,7 @@ static int build_multable(ecl_hip* h, u32 W, u32** out) {
   hipLaunchKernelGGL(k_mul_g, dim3((nlad + 63) / 64), dim3(64), 0, h->stream, lad_k.p, lad.p, (u8*)nullptr, nlad);
   HIPCHK(h, hipGetLastError());
   // rows: launches of ~2^18 threads (one thread per 16 entries), the parking space of one launch reused by the next
-  const u32 nt = (tb.per + 15u) / 16u;
+  const u32 nt = ((tb.stride > tb.top_cnt ? tb.stride : tb.top_cnt) + 15u) / 16u;
   u32 rows = (1u << 18) / nt;
   rows = rows < 1 ? 1 : (rows > tb.nwin ? tb.nwin : rows);
   HIPCHK(h, hipMalloc(&tmp.p, (size_t)rows * 16 * 36 * nt * sizeof(u32)));
@@ -89,12 +89,12 @@ static int build_multable(ecl_hip* h, u32 W, u32** out) {
   std::vector<u32> wk;
   u64 z = 0xD1B54A32D192ED03ull;
   for (u32 w = 0; w < tb.nwin; ++w) {
-    const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
+    const u32 count = wtab_row_count(tb, w);
     for (u32 i = 0; i < PERW; ++i) {
       z ^= z << 13, z ^= z >> 7, z ^= z << 17;
       const u32 b = i == 0 ? 1u : i == 1 ? count : i < 18 ? (i - 1u) : i < 34 ? (i - 17u) * 16u + (i & 1u) : (u32)(z % count) + 1u;
       const u32 digit = b > count ? count : b;
-      sl.push_back((u64)w * tb.per + digit - 1);
+      sl.push_back((u64)w * tb.stride + digit - 1);
       u32 kw[8];
       words_of(kw, sc_mul_u64(sc_pow2(W * w), digit));
       wk.insert(wk.end(), kw, kw + 8);
@@ -162,7 +162,7 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
   if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
   if (!h->copy_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MUL_NBUF; ++i) {
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
     }
@@ -172,7 +172,7 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
   if (want > h->kbuf_cap) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MUL_NBUF; ++i) {
       if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
       if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
       h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
@@ -180,7 +180,7 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
     h->pin_cap = 0;
     if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
     h->d_multmp = nullptr, h->kbuf_cap = 0;
-    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
+    for (int i = 0; i < MUL_NBUF; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
     // the kernel indexes the planes as r * 36 * nt + plane * nt + t with nt = ceil(m / R) rounded up to whole workgroups:
     // up to R * 256 * C slots more than m (C <= MUL_CMAX chains per summing thread)
     // (+ 10 words per thread behind the planes: the chain products and infinity masks that k_mul_sum hands to k_mul_finish)
@@ -290,14 +290,15 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
       else (void)hipGetLastError();
     }
   }
-  if (!direct)
-    for (int i = 0; i < 2; ++i)
-      if (!h->pin_k[i] || h->pin_cap < h->kbuf_cap) {
-        if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
-        h->pin_k[i] = nullptr;
-        HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)h->kbuf_cap * 32, hipHostMallocDefault));
-        if (i == 1) h->pin_cap = h->kbuf_cap;
-      }
+  if (!direct && (!h->pin_k[0] || h->pin_cap < h->kbuf_cap)) {
+    for (int i = 0; i < MUL_NBUF; ++i) {
+      if (h->pin_k[i]) HIPCHK(h, hipHostFree(h->pin_k[i]));
+      h->pin_k[i] = nullptr;
+    }
+    h->pin_cap = 0;
+    for (int i = 0; i < MUL_NBUF; ++i) HIPCHK(h, hipHostMalloc(&h->pin_k[i], (size_t)h->kbuf_cap * 32, hipHostMallocDefault));
+    h->pin_cap = h->kbuf_cap;
+  }
   add_args a;
   memset(&a, 0, sizeof a);
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
@@ -324,9 +325,9 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
-    const u32 b = c & 1;
+    const u32 b = c % MUL_NBUF;
     m = n - at < lim ? n - at : lim;
-    if (c >= 2) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel two chunks back is done with this pair
+    if (c >= MUL_NBUF) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel MUL_NBUF pieces back is done with this buffer (and its staging twin)
     const void* src = scalars[at];
     if (!direct) memcpy(h->pin_k[b], scalars[at], (size_t)m * 32), src = h->pin_k[b];
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));

@@ -116,11 +116,15 @@ struct xyzz {
   fe X, Y, ZZ, ZZZ;
   u32 inf;
 };
-FE_FN xyzz xyzz_madd_lazy(const xyzz& p, const fe& qx, const fe& qy) {
-  const fe u2 = fe_mul(qx, p.ZZ), s2 = fe_mul(qy, p.ZZZ);
+// neg != 0: P - Q, i.e. (qx, -qy) is added: the sign goes on s2 = qy ZZZ (one select per limb, inside the sum that is normalised anyway)
+FE_FN xyzz xyzz_madd_lazy(const xyzz& p, const fe& qx, const fe& qy, u32 neg = 0) {
+  const fe u2 = fe_mul(qx, p.ZZ), s2p = fe_mul(qy, p.ZZZ), s2m = fe_neg(s2p, 1);
+  fe s2;
+#pragma unroll
+  for (int l = 0; l < FE_LIMBS; ++l) s2.n[l] = neg ? s2m.n[l] : s2p.n[l];
   fe h = fe_sub(u2, p.X);                   // magnitude 3
   fe_normalize_weak(h);
-  fe rr = fe_add(s2, fe_neg(p.Y, 3));       // magnitude 5
+  fe rr = fe_add(s2, fe_neg(p.Y, 3));       // magnitude <= 6
   fe_normalize_weak(rr);
   const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(p.X, hh);
   xyzz r;

@@ -39,8 +39,9 @@ struct ecl_hip {
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
   uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
-  // `mul`: scalars travel in chunks through two pinned staging buffers, copy engine and kernel overlapped
-  u32* d_kbuf[2] = {nullptr, nullptr}; u32* pin_k[2] = {nullptr, nullptr}; u32 kbuf_cap = 0, pin_cap = 0;
+  // `mul`: scalars travel in pieces through MUL_NBUF device buffers (and as many pinned staging buffers for pageable callers), the copy
+  // engine running up to MUL_NBUF - 1 pieces ahead of the kernel
+  u32* d_kbuf[MUL_NBUF] = {}; u32* pin_k[MUL_NBUF] = {}; u32 kbuf_cap = 0, pin_cap = 0;
   u32* d_multmp = nullptr;                     // parked Jacobian sums of one chunk (144 bytes per scalar)
   const u32* d_multab = nullptr; u32 multab_W = 0;  // `mul`'s window table in use: one per (device, width), shared by the contexts
   u32 mul_W_fixed = 0;                         // ecl_hip_set_mul_window: 0 = automatic
@@ -49,7 +50,7 @@ struct ecl_hip {
   void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
   u32* d_rawtext = nullptr; size_t rawtext_cap = 0; u64* d_rawlines = nullptr; u32 rawlines_cap = 0;  // `mul -raw`: text and line table of one call
   hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  hipEvent_t ev_copied[MUL_NBUF] = {}, ev_free[MUL_NBUF] = {};
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
@@ -150,7 +151,7 @@ void ecl_hip_close(ecl_hip* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MUL_NBUF; ++i) {
     (void)hipFree(h->d_kbuf[i]);
     if (h->pin_k[i]) (void)hipHostFree(h->pin_k[i]);
     if (h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);

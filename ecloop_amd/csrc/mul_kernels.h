@@ -10,6 +10,9 @@
 // <= 19 mixed additions of table points per scalar (64-byte gathers, the 19.9 MB table lives in L2 / Infinity Cache).
 // The scalar 0 (mod n) yields no point (the reference emits garbage).
 #define GT_W 14u
+#ifndef MUL_NBUF
+#define MUL_NBUF 4  /* staging buffers of ecl_hip_mul_batch: the copy engine runs up to MUL_NBUF - 1 pieces ahead of the kernel */
+#endif
 #define MUL_CHUNK (1u << 22)  /* scalars per staged chunk of ecl_hip_mul_batch (128 MB): 2^18 threads x MUL_R */
 #define GT_WINDOWS 19u
 #define GT_PER ((1u << GT_W) - 1u)
@@ -38,29 +41,39 @@ __device__ __forceinline__ jac gtable_sum(const u32 kk[9], const u32* __restrict
 __device__ __forceinline__ jac gtable_mul(const u32 kk[9], const u32* __restrict__ gtab) { return gtable_sum<GT_W, GT_WINDOWS>(kk, gtab); }
 
 // ---- `mul` has its own window tables, sized for HBM.  The reference's W = 14 (19 windows, 19.9 MB) is sized for a CPU's
-// cache (lib/ecc.c:876, `bench-gtable` sweeps it); on a 288 GB part W = 22 costs 3.0 GB and turns 19 additions per
-// scalar into 12 (one per non-zero digit).  Same method, same results; measured on 2^24-scalar calls, -a cu, device
-// time: W = 14 725 M scalars/s, 16 811, 18 842, 20 878, 22 919, 24 (11.8 GB) 965 (profiles/r03_mul_w_sweep.txt).
-// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 20, 809 MB,
-// and moves to W = 22 once it has seen enough scalars to pay for the 50 ms build: ecl_hip_mul_batch).
+// cache (lib/ecc.c:876, `bench-gtable` sweeps it); on a 288 GB part W = 26 costs 19.6 GB and turns 19 additions per
+// scalar into 10 (one per non-zero digit).  Same method, same results; measured on 2^26-scalar calls, -a cu (profiles/
+// r04_mul_w_sweep.txt): W = 20 1048 M scalars/s, 22 1156, 24 1208-1232, 25 1221, 26 1285-1297.
+// The width is a run-time property of the table (ecl_hip_set_mul_window; by default a context starts on W = 22, 1.5 GB,
+// and moves to W = 26 once it has seen enough scalars to pay for the build: ecl_hip_mul_batch).
 // The rows are not built by millions of double-and-add ladders but the way the walk's lane centres are: row w is
 // P_w, 2 P_w, 3 P_w, ... with P_w = 2^(W w) G - the points C0 + g D of k_init_centres_batched with C0 = D = P_w -
 // 44 multiplications per entry, one inversion per 16 entries; the ladder points 2^j P_w of every row come from one
 // k_mul_g launch.
+// Signed digits (round 4): a window's digit d in [0, 2^W) is taken as d - 2^W with a carry into the next window when it is above
+// 2^(W-1), and a negative digit adds the NEGATED table point (same x, p - y): a row holds 2^(W-1) points instead of 2^W - 1, so a
+// table of a given size is one bit wider - 26 bits (10 additions per scalar) in 19.6 GB, where the unsigned layout needed 43 GB.
+// The last window is not recoded (its carry would have nowhere to go): its row holds 2^topbits points, topbits = 256 - W (nwin - 1).
 struct wtab {
-  const u32* p;  // slot per * w + b - 1 = b * 2^(W w) * G, canonical x[8], y[8]
-  u32 W, nwin, per, top_per;  // bits per window, windows = ceil(256 / W), 2^W - 1, entries of the last row
+  const u32* p;  // slot stride * w + m - 1 = m * 2^(W w) * G, canonical x[8], y[8]
+  u32 W, nwin, per, half, stride, top_cnt;  // bits per window, windows = ceil(256 / W), 2^W - 1, 2^(W-1), slots per row, slots of the last row
 };
 __host__ __device__ inline wtab wtab_make(const u32* p, u32 W) {
   wtab t;
   t.p = p, t.W = W, t.nwin = (256u + W - 1u) / W, t.per = (1u << W) - 1u;
-  t.top_per = (1u << (256u - W * (t.nwin - 1u))) - 1u;
+  t.half = 1u << (W - 1u), t.stride = t.half;
+  t.top_cnt = 1u << (256u - W * (t.nwin - 1u));
   return t;
 }
-__host__ __device__ inline size_t wtab_slots(const wtab& t) { return (size_t)(t.nwin - 1u) * t.per + t.top_per; }
-#ifndef ECL_WTAB_PREFETCH
-#define ECL_WTAB_PREFETCH 1  /* 0: load a window's point when it is added (A/B) */
-#endif
+__host__ __device__ inline size_t wtab_slots(const wtab& t) { return (size_t)(t.nwin - 1u) * t.stride + t.top_cnt; }
+__host__ __device__ inline u32 wtab_row_count(const wtab& t, u32 w) { return w == t.nwin - 1u ? t.top_cnt : t.stride; }
+// window w's digit with the carry of the window below: magnitude (0 = nothing to add, else slot m - 1 of row w), sign, carry out
+__host__ __device__ __forceinline__ u32 wtab_recode(const wtab& t, u32 w, u32 raw, u32& carry, u32& neg) {
+  const u32 v = raw + carry;  // 0 .. 2^W
+  const bool n = w + 1u < t.nwin && v > t.half;
+  carry = n ? 1u : 0u, neg = carry;
+  return n ? t.per + 1u - v : v;
+}
 __device__ __forceinline__ u32 wtab_digit(const u32 kk[9], const wtab& t, u32 w) {
   const u32 bit = w * t.W, word = bit >> 5, sh = bit & 31;
   u32 lo = 0, hi = 0;
@@ -68,43 +81,32 @@ __device__ __forceinline__ u32 wtab_digit(const u32 kk[9], const wtab& t, u32 w)
   for (int j = 0; j < 8; ++j) {  // static indexing keeps kk[] in registers
     if (word == (u32)j) lo = kk[j], hi = kk[j + 1];
   }
-  return (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // kk[8] = 0: the last window is as narrow as it is
+  return (u32)((((u64)hi << 32 | lo) >> sh) & t.per);  // raw digit; kk[8] = 0: the last window is as narrow as it is
 }
 // The point of window w + 1 is requested before the addition of window w's (64 bytes, 16 registers held across one
 // mixed addition): the gathers come from HBM / Infinity Cache and the kernel runs at two waves per SIMD, too few to hide them.
 // Measured on 2^24-scalar calls, 22-bit table, four processes each: 995-1001 M scalars/s with, 980-985 without.
+// -y for a negative digit, magnitude 1 (the complete formulas and the first two points of a lazy sum take normalised operands)
+__device__ __forceinline__ fe fe_cneg_weak(const fe& y, u32 neg) {
+  const fe m = fe_neg(y, 1);
+  fe r;
+#pragma unroll
+  for (int l = 0; l < FE_LIMBS; ++l) r.n[l] = neg ? m.n[l] : y.n[l];
+  fe_normalize_weak(r);
+  return r;
+}
 __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
   jac acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
-#if ECL_WTAB_PREFETCH
-  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  u32 dnext = wtab_digit(kk, t, 0);
-  if (dnext) {
-    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
-    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-  }
+  u32 carry = 0;
 #pragma unroll 1
   for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = dnext;
-    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
-    if (dnext) {
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
-      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-    }
-    if (!digit) continue;
-    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-    acc = jac_madd(acc, fe_from_words(xw), fe_from_words(yw));
+    u32 neg;
+    const u32 m = wtab_recode(t, w, wtab_digit(kk, t, w), carry, neg);
+    if (!m) continue;
+    const u32* e = t.p + ((size_t)w * t.stride + m - 1) * 16;
+    acc = jac_madd(acc, fe_ldw(e), fe_cneg_weak(fe_ldw(e + 8), neg));
   }
-#else
-#pragma unroll 1
-  for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = wtab_digit(kk, t, w);
-    if (!digit) continue;
-    const u32* e = t.p + ((size_t)w * t.per + digit - 1) * 16;
-    acc = jac_madd(acc, fe_ldw(e), fe_ldw(e + 8));
-  }
-#endif
   return acc;
 }
 #ifndef ECL_MUL_MMADD
@@ -119,25 +121,25 @@ __device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { r
 __device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
   jac acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
-  u32 npts = 0;
+  u32 npts = 0, carry = 0, nneg = 0;
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  u32 dnext = wtab_digit(kk, t, 0);
+  u32 dnext = wtab_recode(t, 0, wtab_digit(kk, t, 0), carry, nneg);
   if (dnext) {
     const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
     n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
   }
 #pragma unroll 1
   for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = dnext;
+    const u32 digit = dnext, neg = nneg;
     const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    dnext = w + 1 < t.nwin ? wtab_recode(t, w + 1, wtab_digit(kk, t, w + 1), carry, nneg) : 0u;
     if (dnext) {
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.stride + dnext - 1) * 16);
       n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
     if (!digit) continue;
     const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-    const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
+    const fe qx = fe_from_words(xw), qy = fe_cneg_weak(fe_from_words(yw), neg);
     if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
 #if ECL_MUL_MMADD
     else if (npts == 1) acc = jac_mmadd_lazy(acc.X, acc.Y, qx, qy);
@@ -155,28 +157,29 @@ __device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
 __device__ __forceinline__ xyzz wtab_sum_xyzz(const u32 kk[9], const wtab t) {
   xyzz acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.ZZ = fe_one(), acc.ZZZ = fe_one(), acc.inf = 1;
-  u32 npts = 0;
+  u32 npts = 0, carry = 0, nneg = 0;
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  u32 dnext = wtab_digit(kk, t, 0);
+  u32 dnext = wtab_recode(t, 0, wtab_digit(kk, t, 0), carry, nneg);
   if (dnext) {
     const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
     n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
   }
 #pragma unroll 1
   for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = dnext;
+    const u32 digit = dnext, neg = nneg;
     const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    dnext = w + 1 < t.nwin ? wtab_digit(kk, t, w + 1) : 0u;
+    dnext = w + 1 < t.nwin ? wtab_recode(t, w + 1, wtab_digit(kk, t, w + 1), carry, nneg) : 0u;
     if (dnext) {
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.per + dnext - 1) * 16);
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.stride + dnext - 1) * 16);
       n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
     if (!digit) continue;
     const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
     const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
-    if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
-    else if (npts == 1) acc = xyzz_mmadd_lazy(acc.X, acc.Y, qx, qy);
-    else acc = xyzz_madd_lazy(acc, qx, qy);
+    // the first two points take their sign on y (normalised: they are subtracted from each other), the later ones on s2 = y ZZZ
+    if (npts == 0) acc.X = qx, acc.Y = fe_cneg_weak(qy, neg), acc.inf = 0;
+    else if (npts == 1) acc = xyzz_mmadd_lazy(acc.X, acc.Y, qx, fe_cneg_weak(qy, neg));
+    else acc = xyzz_madd_lazy(acc, qx, qy, neg);
     ++npts;
   }
   return acc;
@@ -187,11 +190,11 @@ __global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ lad
                                                       u32 W, u32 w0) {
   const wtab tb = wtab_make(table, W);
   const u32 w = w0 + blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
-  const u32 count = w == tb.nwin - 1u ? tb.top_per : tb.per;
+  const u32 count = wtab_row_count(tb, w);
   const u32 g0 = t * 16u;
   if (t >= nt || g0 >= count) return;
   const u32* ladder = ladders + (size_t)w * 32 * 16;
-  u32* out = table + (size_t)w * tb.per * 16;
+  u32* out = table + (size_t)w * tb.stride * 16;
   u32* tmp = tmp_all + (size_t)blockIdx.y * 16 * 36 * nt;
   jac acc;
   acc.X = fe_ldw(ladder), acc.Y = fe_ldw(ladder + 8), acc.Z = fe_one(), acc.inf = 0;
@@ -358,40 +361,46 @@ __device__ __forceinline__ u32 wtab_digit_mem(const u32* __restrict__ kw, const 
   u32 bit = w * t.W, word = bit >> 5, sh = bit & 31u;
   if (word > 6u) word = 6u, sh += 32u;  // the last words: shift further instead of reading past the scalar
   const u64 v = *(const u64*)(kw + word);  // 4-byte aligned 8-byte load
-  return (u32)(v >> sh) & t.per;
+  return (u32)(v >> sh) & t.per;  // raw digit
 }
 __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad) {
-  u32 d0 = wtab_digit_mem(kw, t, 0), d1 = wtab_digit_mem(kw, t, 1), dn = t.nwin > 2u ? wtab_digit_mem(kw, t, 2) : 1u;
+  u32 carry = 0, s0, s1, sn = 0;
+  u32 d0 = wtab_recode(t, 0, wtab_digit_mem(kw, t, 0), carry, s0), d1 = wtab_recode(t, 1, wtab_digit_mem(kw, t, 1), carry, s1);
+  u32 dn = t.nwin > 2u ? wtab_recode(t, 2, wtab_digit_mem(kw, t, 2), carry, sn) : 1u;
   bad = (d0 == 0u) | (d1 == 0u);
   d0 = d0 ? d0 : 1u, d1 = d1 ? d1 : 1u;
   xyzz acc;
   {
     const uint4* e0 = (const uint4*)(t.p + ((size_t)d0 - 1) * 16);
-    const uint4* e1 = (const uint4*)(t.p + ((size_t)t.per + d1 - 1) * 16);
+    const uint4* e1 = (const uint4*)(t.p + ((size_t)t.stride + d1 - 1) * 16);
     const uint4 a0 = e0[0], a1 = e0[1], a2 = e0[2], a3 = e0[3], b0 = e1[0], b1 = e1[1], b2 = e1[2], b3 = e1[3];
     const u32 pxw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pyw[8] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
     const u32 qxw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, qyw[8] = {b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_from_words(pyw), fe_from_words(qxw), fe_from_words(qyw));
+    acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_cneg_weak(fe_from_words(pyw), s0), fe_from_words(qxw), fe_cneg_weak(fe_from_words(qyw), s1));
   }
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
   if (t.nwin > 2u) {
     bad |= dn == 0u;
     dn = dn ? dn : 1u;
-    const uint4* e = (const uint4*)(t.p + ((size_t)2 * t.per + dn - 1) * 16);
+    const uint4* e = (const uint4*)(t.p + ((size_t)2 * t.stride + dn - 1) * 16);
     n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
   }
 #pragma unroll 1
   for (u32 w = 2; w < t.nwin; ++w) {
     const u32 xw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w}, yw[8] = {n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
     const bool more = w + 1u < t.nwin;
-    dn = more ? wtab_digit_mem(kw, t, w + 1u) : 1u;
-    const fe u2 = fe_mul(fe_from_words(xw), acc.ZZ), s2 = fe_mul(fe_from_words(yw), acc.ZZZ);
+    const u32 neg = sn;
+    dn = more ? wtab_recode(t, w + 1u, wtab_digit_mem(kw, t, w + 1u), carry, sn) : 1u;
+    const fe u2 = fe_mul(fe_from_words(xw), acc.ZZ), s2p = fe_mul(fe_from_words(yw), acc.ZZZ), s2m = fe_neg(s2p, 1);
     if (more) {
       bad |= dn == 0u;
       dn = dn ? dn : 1u;
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1u) * t.per + dn - 1) * 16);
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1u) * t.stride + dn - 1) * 16);
       n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
+    fe s2;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) s2.n[l] = neg ? s2m.n[l] : s2p.n[l];
     fe h = fe_sub(u2, acc.X);
     fe_normalize_weak(h);
     fe rr = fe_add(s2, fe_neg(acc.Y, 3));

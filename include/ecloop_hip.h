@@ -129,10 +129,11 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
 
 /* `mul` command body (main.c:530-534): public keys of n scalars, hash, probe; key_offset = scalar index.
    The fixed-base window table of ec_gtable_mul (lib/ecc.c:876-929) is built on the device at a window width sized for
-   HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB): a context starts on 20 bits (13 rows, 12 * (2^20 - 1) + 65535 points of 64 bytes = 809 MB, a few
-   ms) and moves to 22 bits (12 rows, 3.2 GB, ~50 ms: 12 additions per scalar instead of 19) once it has multiplied 2^30
-   scalars, which is when the wider table has paid for its build (24 bits, 11.8 GB, is another 5-9 % faster and can be asked for
-   with ecl_hip_set_mul_window; 26 bits is accepted and slower: its gathers leave the TLB's reach).  A table is checked against the double-and-add kernel
+   HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB), with signed digits (a row holds 2^(W-1) points, a digit above
+   2^(W-1) adds the negated point and carries): a context starts on 22 bits (12 rows, 11 * 2^21 + 2^14 points of 64 bytes = 1.5 GB,
+   ~40 ms with the first call) and moves to 26 bits (10 rows, 19.6 GB, ~90 ms: 10 additions per scalar instead of 19) once it has
+   multiplied 2^30 scalars, which is when the wider table has paid for its build (any width 8...26 can be fixed with
+   ecl_hip_set_mul_window).  A table is checked against the double-and-add kernel
    on sample slots before use (ECL_E_SELFTEST on a mismatch), shared between the contexts of a device in the process
    and freed with the last of them.  Results do not depend on the width. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,

@@ -322,13 +322,21 @@ def _mul_all_against_double_and_add(d, K):
 
 def _digit_edge_scalars(rng, n, W):
     """random 256-bit scalars plus the digit patterns a W-bit window table can get wrong: every digit at its maximum,
-    a single digit per window (1 and the maximum, the last window's narrower maximum included), 2^256 - 1, n - 1"""
+    a single digit per window (1 and the maximum, the last window's narrower maximum included), 2^256 - 1, n - 1; and what the
+    signed recoding turns on: a digit of exactly 2^(W-1) (the largest that stays positive), 2^(W-1) + 1 (the first that becomes
+    negative with a carry), those in every window at once, a carry that runs through windows of all ones into the last row"""
     K = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, (n, 4), dtype=np.int64).astype(np.uint64)
     special = [(1 << 256) - 1, orc.N - 1, orc.N + 1, 1, 2]
     nwin = (256 + W - 1) // W
     for w in range(nwin):
         width = min(W, 256 - W * w)
         special += [1 << (W * w), ((1 << width) - 1) << (W * w), (((1 << width) - 1) << (W * w)) | 1]
+        if width == W:
+            half = 1 << (W - 1)
+            special += [half << (W * w), (half + 1) << (W * w), ((half + 1) << (W * w)) | (((1 << 256) - 1) >> (W * (w + 1)) << (W * (w + 1)))]
+    M256 = (1 << 256) - 1
+    special += [sum((1 << (W - 1)) << (W * w) for w in range(nwin)) & M256, sum(((1 << (W - 1)) + 1) << (W * w) for w in range(nwin)) & M256,
+                sum(((1 << (W - 1)) - 1) << (W * w) for w in range(nwin)) & M256]
     for i, v in enumerate(special):
         K[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
     return K
@@ -356,7 +364,7 @@ def test_mul_every_window_width_against_double_and_add(W):
 
 
 def test_mul_moves_to_the_long_table_after_2_pow_30_scalars_with_identical_results():
-    """automatic width: 20 bits until the context has seen 2^30 scalars, 22 bits from then on (the call that crosses the
+    """automatic width: 22 bits until the context has seen 2^30 scalars, 26 bits from then on (the call that crosses the
     line already runs on the long table); two contexts on the device share each table; same hits before and after"""
     import ctypes as C
     from ecloop_amd import Device, capi
@@ -374,7 +382,7 @@ def test_mul_moves_to_the_long_table_after_2_pow_30_scalars_with_identical_resul
         for call in range(259):  # 258 * 2^22 > 2^30
             dev = d if call != 64 else d2  # the second context stays on the short table
             assert dev.lib.ecl_hip_mul_batch(dev.h, K.ctypes.data, n, out.ctypes.data, len(out), C.byref(cnt)) == 0
-            assert dev.mul_window() == (22 if dev is d and call >= 256 else 20)  # d's 256th call (call 64 went to d2) completes 2^30
+            assert dev.mul_window() == (26 if dev is d and call >= 256 else 22)  # d's 256th call (call 64 went to d2) completes 2^30
             if call in (0, 64, 254, 255, 256, 258):
                 r = out[: cnt.value]
                 hits.append(sorted(zip(r["key_offset"].tolist(), map(tuple, r["h160"].tolist()))))

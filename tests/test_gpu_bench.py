@@ -54,7 +54,7 @@ def test_bench_secondary_legs_at_reduced_size():
     assert c2["roofline"]["kernel"] == "k_add<addr33,addr65,endo>" and c2["roofline"]["keys_per_launch"] == 1 << 27
     assert c3["windows"] == 1 and c3["config"]["checked"] == 1 << 32 and c3["config"]["found_list_matches_oracle_on_sample"] and c3["value"] > 3000
     assert 0 < c3["config"]["setup_share"] < 0.05
-    assert api["config"]["found_list_matches_oracle_on_sample"] and api["config"]["window_bits"] == 22 and api["value"] > 100
+    assert api["config"]["found_list_matches_oracle_on_sample"] and api["config"]["window_bits"] == 26 and api["value"] > 100
     assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
     assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
     for leg in (c2, api):  # rooflines priced with the kernels' own PMC profiles when those are in the tree
@@ -122,5 +122,5 @@ def test_bench_cmd_mul_line():
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
     r = last_json(pr.stdout)
-    assert r["unit"] == "Mscalars/s" and r["config"]["window_bits"] == 22 and r["n_gpus"] == 1
+    assert r["unit"] == "Mscalars/s" and r["config"]["window_bits"] == 26 and r["n_gpus"] == 1
     assert abs(r["value"] - (1 << 21) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3 and r["value"] > 100

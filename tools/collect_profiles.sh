@@ -92,7 +92,7 @@ if want mul; then
 : > "$O/pmc_mul.txt"
 for set in "SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "VALUBusy"; do
   ECL_HIP_SKIP_SELFTEST=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmcm" -o p -- python "$R/bench.py" --cmd mul --steps 1 --warmup 1 > "$O/pmcm.log" 2>&1
-  echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 3 x 2^24 scalars, -a cu, 22-bit window table)" >> "$O/pmc_mul.txt"
+  echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 3 x 2^24 scalars, -a cu, 26-bit window table)" >> "$O/pmc_mul.txt"
   summ "$O/pmcm" k_mul >> "$O/pmc_mul.txt"
   rm -rf "$O/pmcm"
 done

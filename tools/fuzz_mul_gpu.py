@@ -2,7 +2,7 @@
 """Differential fuzz of the `mul` path on the GPU box: random batch sizes (1 .. 2^22+, so that 1, 2, 4, 8 and 16 scalars
 per thread and several staged chunks all occur), random 256-bit scalars with zeros / n / small values mixed in,
 address selections, filters of several sizes and densities, pageable and page-locked scalar arrays, the window width of the
-table fixed at random (8 .. 24 bits) or automatic; every third trial feeds text lines to ecl_hip_mul_batch_raw (`mul -raw`:
+table fixed at random (8 .. 26 bits) or automatic; every third trial feeds text lines to ecl_hip_mul_batch_raw (`mul -raw`:
 SHA-256 of the line on the device; lengths 0 .. 300, any alignment) with hashlib's digests as the scalars of the yardstick.
 Every hit set of ecl_hip_mul_batch / _raw (window table + ONE inversion per thread) must equal the one derived independently:
 double-and-add kernel -> hash kernel -> the oracle's blf_has on the host.
@@ -39,14 +39,15 @@ def main():
         for _ in range(min(n, 6)):  # edge scalars at random places: 0, n (both infinity), 1, n-1, 2^14-1, a value above n
             i = rnd.randrange(n)
             K[i] = rnd.choice([np.zeros(4, np.uint64), N_LIMBS, np.array([1, 0, 0, 0], np.uint64), N_LIMBS - np.array([1, 0, 0, 0], np.uint64),
-                               np.array([(1 << 14) - 1, 0, 0, 0], np.uint64), np.full(4, 0xFFFFFFFFFFFFFFFF, np.uint64)])
+                               np.array([(1 << 14) - 1, 0, 0, 0], np.uint64), np.full(4, 0xFFFFFFFFFFFFFFFF, np.uint64),
+                               np.full(4, 0x8000000000000000, np.uint64), np.full(4, 0x8000000080000000, np.uint64), np.full(4, 0x7FFFFFFFFFFFFFFF, np.uint64)])
         nw = rnd.choice([1, 64, 4099, 65539, (1 << 20) + 7])
         mode = rnd.choice(["a|b", "a|(b&c)", "a", "ones"])
         words = np.full(nw, 0xFFFFFFFFFFFFFFFF, np.uint64) if mode == "ones" else synth_bloom_words(nw, rnd.randrange(1 << 30), mode)
         if mode == "ones" and n > (1 << 20):
             words = synth_bloom_words(nw, 7, "a|b")  # keep the record count of the big batches moderate
         pinned = rnd.random() < 0.5
-        window = rnd.choice([0, 0, rnd.randrange(8, 25)])
+        window = rnd.choice([0, 0, rnd.randrange(8, 25), rnd.randrange(8, 27)])
         raw = trials % 3 == 2
         if raw:  # the scalars ARE the SHA-256 digests of random lines
             import hashlib

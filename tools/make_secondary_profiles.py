@@ -69,7 +69,7 @@ def profile(path, tag, kernel, workload, units, unit_name):
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     jobs = [("pmc_mul.txt", "roofline_mul", "mul kernels (k_mul*: window sums, hash160, probe)",
-             "bench.py --cmd mul --steps 1 --warmup 1: 3 calls of 2^24 scalars from page-locked host memory, -a cu, 22-bit window table", 3 * (1 << 24), "scalar"),
+             "bench.py --cmd mul --steps 1 --warmup 1: 3 calls of 2^24 scalars from page-locked host memory, -a cu, 26-bit window table", 3 * (1 << 24), "scalar"),
             ("pmc_cu_endo.txt", "roofline_cu_endo", "k_add<addr33,addr65,endo>",
              "bench.py --addr cu --endo --filter-n 1100000000 --keys-log2 30: one 2^30-key launch, 12 hash160 per key, 5.9 GB filter", 1 << 30, "key")]
     for src, kind, kernel, workload, units, unit in jobs:
