@@ -306,18 +306,17 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  // A call is cut into pieces so that the copy engine runs one piece ahead of the kernel: a first piece of 2^18 scalars (nothing
-  // overlaps its copy), then pieces of 2^20, or 2^21 for calls of 2^25 scalars and more.  Kernel time per piece on 2^26-scalar calls
-  // (tools/mul_kernel_times.sh, profiles/r04_mul_ab.txt): 2^20 scalars (8 per thread) 0.977 ms = 1.07 G scalars/s, 2^21 (16 per
-  // thread) 1.850 ms = 1.13 G/s, 2^22 (32 per thread) 3.999 ms = 1.05 G/s - sharing the inversion among more scalars stops paying at
-  // 16 per thread (the parked sums of a piece no longer stay in the Infinity Cache: 604 MB at 2^22), and a long piece lengthens the
-  // pipeline's fill and drain.  Pieces that double (2^18 ... 2^22): 932 M scalars/s on 2^24-scalar calls against 1007 - with two
-  // staging buffers the copy of piece c + 1 starts when the kernel of piece c - 1 ends, and a piece twice as long as the last does
-  // not arrive in time.  Fewer than 2^17 threads per kernel cost more than they save; 196 608 or 262 144 threads do too (829 / 1075
-  // against 1097 M scalars/s).
+  // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4 and then 8
+  // scalars per resident thread (16 for calls of 2^25 scalars and more), i.e. 2^17, 2^18, 2^19, 2^20 (2^21) scalars at two waves per SIMD -
+  // each copy is as long as the kernel before it.  Kernel time per piece on 2^26-scalar calls (tools/mul_kernel_times.sh,
+  // profiles/r04_mul_split.txt): 8 scalars per thread 0.888 ms = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s; 32 per
+  // thread lose (round 4, first half: the parked sums of a piece no longer stay in the Infinity Cache: 604 MB at 2^22), and a long piece
+  // lengthens the pipeline's fill and drain.  tools/ab_mul_sched.sh (profiles/r04_mul_sched.txt): this schedule 1222-1230 / 1261-1270 M
+  // scalars/s on 2^24 / 2^26-scalar calls, a first piece of 2^18 followed at once by full pieces (round 3's) 1214 / 1253, top pieces of 16
+  // per thread on 2^24-scalar calls 1187; two staging buffers instead of four 1208 / 1249.
   // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
-  static const u32 first_R = getenv("ECL_HIP_MUL_FIRST_R") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST_R")) : 2u;   // tuning hooks (A/B runs)
-  static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 1600u;
+  static const u32 first_R = getenv("ECL_HIP_MUL_FIRST_R") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST_R")) : 1u;   // tuning hooks (A/B runs)
+  static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 200u;
   static const u32 top_R = getenv("ECL_HIP_MUL_TOP_R") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP_R")) : 0u;
   const u64 unit = (u64)mul_nt_target() * mul_chains_per_thread();
   const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 25) ? 16u : 8u));

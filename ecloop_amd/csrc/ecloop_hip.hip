@@ -444,14 +444,18 @@ extern "C" int ecl_hip_get_geometry(ecl_hip* h, uint32_t* half_group, uint32_t* 
 }
 
 // Geometry of one call.  The table for half group h->B holds the tables of all smaller ones as prefixes.  A call too
-// short to give every one of the Tmax lanes a whole group takes a smaller half group (down to 256) instead of fewer
+// short to give every one of the Tmax lanes a whole group takes a smaller half group (down to 128) instead of fewer
 // lanes: the walk only reaches its rate when the chip is oversubscribed with blocks in different phases (2^29 keys:
-// 11.5 Gkeys/s with 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion: 270 / 2B
-// multiplications per key).  Contiguous calls of one size keep one geometry, so they still continue the resident walk.
+// 11.5 Gkeys/s with 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion - one per
+// lane and group - which is why the floor was 256 while the inversion was the 270-multiplication chain; with the
+// division steps (fe256.h) 128 x 2^21 lanes is ahead on 2^29-key calls: kernel 12.46 against 12.37 Gkeys/s, whole step
+// 12.26 against 12.21 with its longer lane set-up, profiles/r04_short_calls.txt).  Contiguous calls of one size keep one
+// geometry, so they still continue the resident walk.
+#define ECL_B_FLOOR 128u
 static void call_geometry(const ecl_hip* h, u64 nkeys, u32& B, u32& nb, u32& T) {
   B = h->B;
   if (h->B_auto)
-    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+    while (B > ECL_B_FLOOR && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
   const u64 group = 2ull * B, ngroups = (nkeys + group - 1) / group;
   // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
   // through a mostly masked last group
@@ -465,7 +469,7 @@ static bool nkeys_ok(const ecl_hip* h, u64 nkeys) {
   if (nkeys > (1ull << 63)) return false;
   u32 B = h->B;
   if (h->B_auto)
-    while (B > 256 && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+    while (B > ECL_B_FLOOR && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
   const u64 ngroups = (nkeys + 2ull * B - 1) / (2ull * B);
   return (ngroups + h->Tmax - 1) / h->Tmax < (1ull << 32);
 }

@@ -16,7 +16,7 @@ S=$PWD/ecloop_amd/libecloop_hip.so
 for rep in 1 2; do
   [ -n "$1" ] && run "other NBUF, first 2 x16 top 8/16" $PWD/$1 A=1
   run "shipped default" $S A=1
-  run "first 2 x16 top 8/16 (round 3's)" $S ECL_HIP_MUL_FIRST_R=2 ECL_HIP_MUL_GROW=1600
+  run "first 2 x16 top 8/16 (round 3)" $S ECL_HIP_MUL_FIRST_R=2 ECL_HIP_MUL_GROW=1600
   run "first 1 x2 top 8/16" $S ECL_HIP_MUL_FIRST_R=1 ECL_HIP_MUL_GROW=200
   run "first 2 x2 top 8/16" $S ECL_HIP_MUL_FIRST_R=2 ECL_HIP_MUL_GROW=200
   run "first 1 x2 top 16" $S ECL_HIP_MUL_FIRST_R=1 ECL_HIP_MUL_GROW=200 ECL_HIP_MUL_TOP_R=16
