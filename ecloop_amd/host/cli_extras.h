@@ -109,7 +109,7 @@ static int run_bench_gtable(void) {
     for (int j = 0; j < 4; ++j) x ^= x << 13, x ^= x >> 7, x ^= x << 17, ks[i][j] = x;
   u64 zeros[64] = {0};
   ecl_found hit[16];
-  for (u32 w = 8; w <= 24; w += 2) {
+  for (u32 w = 8; w <= 26; w += 2) {
     ecl_hip *d = NULL;
     u32 cnt = 0;
     int rc = ecl_hip_open(&d, 0, ECL_ADDR33, 0);
@@ -124,7 +124,7 @@ static int run_bench_gtable(void) {
     if (rc != ECL_OK) { fprintf(stderr, "[!] bench-gtable w=%u: %s (%s)\n", w, ecl_hip_strerror(rc), d ? ecl_hip_last_error(d) : ""); return 1; }
     const double mult = (double)(t2 - t1) / 1e6, one = mult / reps, gent = (double)(t1 - t0) / 1e6 - one;
     const u32 nwin = (256 + w - 1) / w;
-    const double slots = (double)(nwin - 1) * (double)((1u << w) - 1) + (double)((1u << (256 - w * (nwin - 1))) - 1);
+    const double slots = (double)(nwin - 1) * (double)(1u << (w - 1)) + (double)(1u << (256 - w * (nwin - 1)));  // signed digits: 2^(w-1) per row
     printf("w=%02u: %.1fK it/s | gen: %5.2fs | mul: %5.2fs | mem: %8.1fMB\n", w, (double)n * reps / mult / 1000, gent > 0 ? gent : 0, mult,
            slots * 64 / 1024 / 1024);
     fflush(stdout);

@@ -179,12 +179,12 @@ def test_mult_verify_and_bench_gtable_commands(cli):
     assert pr.returncode == 0 and pr.stdout == b"", pr.stdout + pr.stderr
     pr = subprocess.run([cli, "bench-gtable"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     rows = pr.stdout.decode().splitlines()
-    assert pr.returncode == 0 and len(rows) == 9, pr.stdout + pr.stderr
-    for w, row in zip(range(8, 26, 2), rows):
+    assert pr.returncode == 0 and len(rows) == 10, pr.stdout + pr.stderr
+    for w, row in zip(range(8, 28, 2), rows):
         m = re.fullmatch(r"w=(\d\d): ([\d.]+)K it/s \| gen: +([\d.]+)s \| mul: +([\d.]+)s \| mem: +([\d.]+)MB", row)
         assert m and int(m.group(1)) == w and float(m.group(2)) > 1000, row
-    # w = 14: 18 rows of 16383 points + the 4-bit last window's 15 (the reference allocates 19 full rows: 19.0 MB)
-    assert abs(float(re.search(r"mem: +([\d.]+)MB", rows[3]).group(1)) - 18.0) < 0.1
+    # w = 14, signed digits: 18 rows of 8192 points + the 4-bit last window's 16 (the reference allocates 19 rows of 16383: 19.0 MB)
+    assert abs(float(re.search(r"mem: +([\d.]+)MB", rows[3]).group(1)) - 9.0) < 0.1
 
 
 @pytest.mark.gpu
