@@ -252,6 +252,9 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
+#ifndef ECL_MUL_RINGS
+#define ECL_MUL_RINGS 1  /* A/B: 0 = every hash finishes its filter test in place */
+#endif
 #define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 #ifndef ECL_MUL_WAVES
 #define ECL_MUL_WAVES 2  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side
@@ -260,8 +263,11 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
+#if ECL_MUL_RINGS && ECL_MUL_XYZZ
+  __shared__ u32 q_mem[4][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave (add_kernel.h)
+#endif
   const u32 t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= nt) return;
+  if (t >= nt) return;  // nt is a multiple of 256: whole workgroups leave
   fe prod = fe_one();
   u32 infmask = 0;
 #if ECL_MUL_XYZZ
@@ -289,6 +295,31 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     prod = fe_mul(prod, tt);
   }
   fe inv = fe_inv(prod);
+#if ECL_MUL_RINGS
+  // the filter test through the add kernel's two candidate rings per wave (add_kernel.h: survivors of probe 0 are parked in LDS and
+  // finished 64 at a time): every lane of the wave walks all R rounds - a lane without a scalar (i >= n) or with the point at infinity
+  // comes along with live = false and leaves the inversion chain alone - so that the rings' wave-uniform state stays uniform
+  cand_queues q;
+  q.a.mem = q_mem[threadIdx.x >> 6][0], q.a.head = 0, q.a.count = 0;
+  q.b.mem = q_mem[threadIdx.x >> 6][1], q.b.head = 0, q.b.count = 0;
+#pragma unroll 1
+  for (u32 r = R; r-- > 0;) {
+    const u32 i = r * nt + t;
+    const bool have = i < n;
+    const u32* p = tmp + (size_t)r * 36 * nt + t;
+    fe X, Y, T, pre;
+#pragma unroll
+    for (int l = 0; l < FE_LIMBS; ++l) {
+      X.n[l] = have ? p[(size_t)l * nt] : 0u, Y.n[l] = have ? p[(size_t)(9 + l) * nt] : 0u;
+      T.n[l] = have ? p[(size_t)(18 + l) * nt] : (l == 0 ? 1u : 0u), pre.n[l] = have ? p[(size_t)(27 + l) * nt] : 0u;
+    }
+    const fe ti = fe_mul(inv, pre);
+    inv = fe_mul(inv, T);  // T = 1 for a lane without a scalar in this round
+    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
+    check_point<A33, A65, false>(a, &q, have && !((infmask >> r) & 1u), x, y, (u64)base + i);
+  }
+  cand_flush(a, q);
+#else
 #pragma unroll 1
   for (u32 r = R; r-- > 0;) {
     const u32 i = r * nt + t;
@@ -306,6 +337,7 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
     check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
   }
+#endif
 #else
 #pragma unroll 1
   for (u32 r = 0; r < R; ++r) {

@@ -2,7 +2,8 @@
 """`mul` path throughput (BASELINE.json configs[4]): seeded 256-bit scalars through ecl_hip_mul_batch from a page-locked
 array (host -> device copy of the scalars included), addr33 + addr65, list filter of the brainwallet hashes.  Prints the
 wall rate of each call and the device-side rate (HIP events over the copies + kernels of the call); the first call
-includes building the window table.  usage: bench_mul.py [log2 n] [calls] [window bits, 0 = automatic]"""
+includes building the window table.  usage: bench_mul.py [log2 n] [calls] [window bits, 0 = automatic] [list|design|empty]
+(filter: the brainwallet list's 128-bits-per-entry filter, a 56 MB synthetic .blf at the design density 0.375, or no bit set)"""
 import ctypes as C
 import os
 import sys
@@ -18,9 +19,17 @@ from ecloop_amd.engine import load_filter  # noqa: E402
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 window = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # 0 = the library's automatic choice
-flt = load_filter(os.path.join(ROOT, "tests", "golden", "btc-bw-hash"))
+kind = sys.argv[4] if len(sys.argv) > 4 else "list"
+if kind == "design":
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import synth_bloom_words
+    words = synth_bloom_words(7000003, 23, "a&(b|c)")
+elif kind == "empty":
+    words = np.zeros(64, dtype=np.uint64)
+else:
+    words = load_filter(os.path.join(ROOT, "tests", "golden", "btc-bw-hash")).words
 d = capi.Device(0, a33=True, a65=True)
-d.set_bloom(flt.words)
+d.set_bloom(words)
 d.set_mul_window(window)
 rng = np.random.RandomState(1)
 ptr = d.lib.ecl_hip_alloc_host(n * 32)
