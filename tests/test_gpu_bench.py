@@ -108,6 +108,21 @@ def test_bench_two_ranks_strong_and_weak_legs(control):
     check_two(last_json(pr.stdout), "torch.distributed.run")
 
 
+def test_bench_ranks_are_matched_to_physical_gpus():
+    """under torch.distributed.run a rank takes device LOCAL_RANK, or - when the launcher shows every rank only its own GPU
+    (HIP_VISIBLE_DEVICES per rank) - device 0 of what it sees; ranks that end up on the SAME physical GPU (told by PCI address over
+    the rendezvous) are refused: one rank more than the box has GPUs, no sharing hook"""
+    import torch
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ECL_BENCH_SHARE_GPU", None)
+    n = ngpu + 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", "29523", os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--keys-log2", "24", "--steps", "1", "--warmup", "0", "--no-cpu"]
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+    assert pr.returncode != 0 and b"distinct GPU(s)" in pr.stderr and b'"metric"' not in pr.stdout
+
+
 def test_bench_refuses_more_gpus_than_the_box_has():
     import torch
     n = torch.cuda.device_count() + 1
