@@ -116,9 +116,31 @@ struct xyzz {
   fe X, Y, ZZ, ZZZ;
   u32 inf;
 };
-// neg != 0: P - Q, i.e. (qx, -qy) is added: the sign goes on s2 = qy ZZZ (one select per limb, inside the sum that is normalised anyway)
+// neg != 0: P - Q, i.e. (qx, -qy) is added: the sign goes on s2 = qy ZZZ (one select per limb, inside the sum that is normalised anyway).
+// The ten field operations of an addition come in five independent pairs; each pair runs as one interleaved instruction stream
+// (fe256.h: fe_mul2 / fe_sqr2 - four accumulator chains instead of two, no wait states between dependent multiply-adds), which is worth
+// 5 % of a multiplication at the two waves per SIMD the `mul` kernel runs at (csrc/tools/femul_bench.hip; ECL_MUL_PAIRS=0: one by one).
+#ifndef ECL_MUL_PAIRS
+#define ECL_MUL_PAIRS 1
+#endif
+FE_FN void fe_mul_pair(fe& r1, fe& r2, const fe& a1, const fe& b1, const fe& a2, const fe& b2) {
+#if ECL_MUL_PAIRS
+  fe_mul2(r1, r2, a1, b1, a2, b2);
+#else
+  r1 = fe_mul(a1, b1), r2 = fe_mul(a2, b2);
+#endif
+}
+FE_FN void fe_sqr_pair(fe& r1, fe& r2, const fe& a1, const fe& a2) {
+#if ECL_MUL_PAIRS
+  fe_sqr2(r1, r2, a1, a2);
+#else
+  r1 = fe_sqr(a1), r2 = fe_sqr(a2);
+#endif
+}
 FE_FN xyzz xyzz_madd_lazy(const xyzz& p, const fe& qx, const fe& qy, u32 neg = 0) {
-  const fe u2 = fe_mul(qx, p.ZZ), s2p = fe_mul(qy, p.ZZZ), s2m = fe_neg(s2p, 1);
+  fe u2, s2p;
+  fe_mul_pair(u2, s2p, qx, p.ZZ, qy, p.ZZZ);
+  const fe s2m = fe_neg(s2p, 1);
   fe s2;
 #pragma unroll
   for (int l = 0; l < FE_LIMBS; ++l) s2.n[l] = neg ? s2m.n[l] : s2p.n[l];
@@ -126,26 +148,31 @@ FE_FN xyzz xyzz_madd_lazy(const xyzz& p, const fe& qx, const fe& qy, u32 neg = 0
   fe_normalize_weak(h);
   fe rr = fe_add(s2, fe_neg(p.Y, 3));       // magnitude <= 6
   fe_normalize_weak(rr);
-  const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(p.X, hh);
+  fe hh, rr2, hhh, v, t1, t2;
+  fe_sqr_pair(hh, rr2, h, rr);
+  fe_mul_pair(hhh, v, hh, h, p.X, hh);
   xyzz r;
   r.inf = 0;
-  r.X = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));  // magnitude 6
+  r.X = fe_add(fe_add(rr2, fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));  // magnitude 6
   fe_normalize_weak(r.X);
-  r.Y = fe_add(fe_mul(rr, fe_sub(v, r.X)), fe_neg(fe_mul(p.Y, hhh), 1));       // magnitude 3
-  r.ZZ = fe_mul(p.ZZ, hh);
-  r.ZZZ = fe_mul(p.ZZZ, hhh);
+  fe_mul_pair(t1, t2, rr, fe_sub(v, r.X), p.Y, hhh);
+  r.Y = fe_add(t1, fe_neg(t2, 1));                                     // magnitude 3
+  fe_mul_pair(r.ZZ, r.ZZZ, p.ZZ, hh, p.ZZZ, hhh);
   return r;
 }
 FE_FN xyzz xyzz_mmadd_lazy(const fe& px, const fe& py, const fe& qx, const fe& qy) {
   fe h = fe_sub(qx, px), rr = fe_sub(qy, py);
   fe_normalize_weak(h);
   fe_normalize_weak(rr);
-  const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(px, hh);
+  fe hh, rr2, hhh, v, t1, t2;
+  fe_sqr_pair(hh, rr2, h, rr);
+  fe_mul_pair(hhh, v, hh, h, px, hh);
   xyzz r;
   r.inf = 0;
-  r.X = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
+  r.X = fe_add(fe_add(rr2, fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
   fe_normalize_weak(r.X);
-  r.Y = fe_add(fe_mul(rr, fe_sub(v, r.X)), fe_neg(fe_mul(py, hhh), 1));
+  fe_mul_pair(t1, t2, rr, fe_sub(v, r.X), py, hhh);
+  r.Y = fe_add(t1, fe_neg(t2, 1));
   r.ZZ = hh, r.ZZZ = hhh;
   return r;
 }

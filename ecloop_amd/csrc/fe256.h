@@ -291,6 +291,100 @@ FE_FN fe fe_sqr(const fe& a) {
   return r;
 }
 
+// Two independent products (two squarings) in one instruction stream.  On gfx950 a v_mad_u64_u32 whose accumulator was written by the
+// instruction right before it costs a wait state (the compiler pads with s_nop: 50 per fe_mul, whose two accumulator chains have
+// unequal lengths in most columns); other waves of the SIMD fill those slots at four waves per SIMD (fe_mul: 623 SIMD-clocks), not at
+// two (713; csrc/tools/femul_bench.hip).  With the accumulations of two multiplications interleaved - four chains - there is always an
+// independent multiply-add to issue: same instructions, no padding.  Used where a kernel runs at two waves per SIMD and has the
+// independent pairs at hand (`mul`: ec.h, xyzz_madd_lazy).
+FE_FN void fe_mul2(fe& r1, fe& r2, const fe& a1, const fe& b1, const fe& a2, const fe& b2) {
+  u64 c1 = 0, d1 = 0, c2 = 0, d2 = 0;
+  const u32 R1 = fe_opaque(FE_R1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    FE_PIN64(d1);
+    d1 += (u64)a1.n[i] * b1.n[8 - i];
+    FE_PIN64(d2);
+    d2 += (u64)a2.n[i] * b2.n[8 - i];
+  }
+  const u32 t81 = (u32)d1 & FE_M, t82 = (u32)d2 & FE_M;
+  d1 >>= 29, d2 >>= 29;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < 9; ++i) {
+      FE_PIN64(d1);
+      d1 += (u64)a1.n[i] * b1.n[9 + k - i];
+      FE_PIN64(d2);
+      d2 += (u64)a2.n[i] * b2.n[9 + k - i];
+    }
+    const u32 u1 = (u32)d1 & FE_M, u2 = (u32)d2 & FE_M;
+    d1 >>= 29, d2 >>= 29;
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      FE_PIN64(c1);
+      c1 += (u64)a1.n[i] * b1.n[k - i];
+      FE_PIN64(c2);
+      c2 += (u64)a2.n[i] * b2.n[k - i];
+    }
+    FE_PIN64(c1);
+    c1 += (u64)u1 * FE_R0;
+    FE_PIN64(c2);
+    c2 += (u64)u2 * FE_R0;
+    r1.n[k] = (u32)c1 & FE_M, r2.n[k] = (u32)c2 & FE_M;
+    c1 >>= 29, c2 >>= 29;
+    FE_PIN64(c1);
+    c1 += (u64)u1 * R1;
+    FE_PIN64(c2);
+    c2 += (u64)u2 * R1;
+  }
+  fe_mul_tail(r1, c1, d1, t81);
+  fe_mul_tail(r2, c2, d2, t82);
+}
+FE_FN void fe_sqr2(fe& r1, fe& r2, const fe& a1, const fe& a2) {
+  u32 x1[9], x2[9];  // doubled operands
+#pragma unroll
+  for (int i = 0; i < 9; ++i) x1[i] = a1.n[i] * 2, x2[i] = a2.n[i] * 2;
+  u64 c1 = 0, d1 = 0, c2 = 0, d2 = 0;
+  const u32 R1 = fe_opaque(FE_R1);
+#define FE_SQ2_COL(acc1, acc2, k)                                            \
+  _Pragma("unroll") for (int i = ((k) > 8 ? (k)-8 : 0); 2 * i < (k); ++i) {  \
+    FE_PIN64(acc1);                                                          \
+    acc1 += (u64)a1.n[i] * x1[(k)-i];                                        \
+    FE_PIN64(acc2);                                                          \
+    acc2 += (u64)a2.n[i] * x2[(k)-i];                                        \
+  }                                                                          \
+  if (((k)&1) == 0) {                                                        \
+    FE_PIN64(acc1);                                                          \
+    acc1 += (u64)a1.n[(k) / 2] * a1.n[(k) / 2];                              \
+    FE_PIN64(acc2);                                                          \
+    acc2 += (u64)a2.n[(k) / 2] * a2.n[(k) / 2];                              \
+  }
+  FE_SQ2_COL(d1, d2, 8)
+  const u32 t81 = (u32)d1 & FE_M, t82 = (u32)d2 & FE_M;
+  d1 >>= 29, d2 >>= 29;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    FE_SQ2_COL(d1, d2, 9 + k)
+    const u32 u1 = (u32)d1 & FE_M, u2 = (u32)d2 & FE_M;
+    d1 >>= 29, d2 >>= 29;
+    FE_SQ2_COL(c1, c2, k)
+    FE_PIN64(c1);
+    c1 += (u64)u1 * FE_R0;
+    FE_PIN64(c2);
+    c2 += (u64)u2 * FE_R0;
+    r1.n[k] = (u32)c1 & FE_M, r2.n[k] = (u32)c2 & FE_M;
+    c1 >>= 29, c2 >>= 29;
+    FE_PIN64(c1);
+    c1 += (u64)u1 * R1;
+    FE_PIN64(c2);
+    c2 += (u64)u2 * R1;
+  }
+#undef FE_SQ2_COL
+  fe_mul_tail(r1, c1, d1, t81);
+  fe_mul_tail(r2, c2, d2, t82);
+}
+
 __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {
 #pragma unroll 1
   for (int i = 0; i < n; ++i) a = fe_sqr(a);

@@ -284,15 +284,17 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
     if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
     infmask |= (acc.inf ? 1u : 0u) << r;
-    const fe tt = acc.inf ? fe_one() : fe_mul(acc.ZZ, acc.ZZZ);
-    const fe xs = fe_mul(acc.X, acc.ZZZ), ys = fe_mul(acc.Y, acc.ZZ);
+    fe tt, xs, ys, nprod;
+    fe_mul_pair(tt, xs, acc.ZZ, acc.ZZZ, acc.X, acc.ZZZ);
+    if (acc.inf) tt = fe_one();
+    fe_mul_pair(ys, nprod, acc.Y, acc.ZZ, prod, tt);
     u32* p = tmp + (size_t)r * 36 * nt + t;
 #pragma unroll
     for (int l = 0; l < FE_LIMBS; ++l) {
       p[(size_t)l * nt] = xs.n[l], p[(size_t)(9 + l) * nt] = ys.n[l];
       p[(size_t)(18 + l) * nt] = tt.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
     }
-    prod = fe_mul(prod, tt);
+    prod = nprod;
   }
   fe inv = fe_inv(prod);
 #if ECL_MUL_RINGS
@@ -313,9 +315,10 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
       X.n[l] = have ? p[(size_t)l * nt] : 0u, Y.n[l] = have ? p[(size_t)(9 + l) * nt] : 0u;
       T.n[l] = have ? p[(size_t)(18 + l) * nt] : (l == 0 ? 1u : 0u), pre.n[l] = have ? p[(size_t)(27 + l) * nt] : 0u;
     }
-    const fe ti = fe_mul(inv, pre);
-    inv = fe_mul(inv, T);  // T = 1 for a lane without a scalar in this round
-    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
+    fe ti, ninv, x, y;
+    fe_mul_pair(ti, ninv, inv, pre, inv, T);  // T = 1 for a lane without a scalar in this round
+    inv = ninv;
+    fe_mul_pair(x, y, X, ti, Y, ti);
     check_point<A33, A65, false>(a, &q, have && !((infmask >> r) & 1u), x, y, (u64)base + i);
   }
   cand_flush(a, q);
