@@ -307,8 +307,8 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
   // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4 and then 8
-  // scalars per resident thread (16 for calls of 2^25 scalars and more), i.e. 2^17, 2^18, 2^19, 2^20 (2^21) scalars at two waves per SIMD -
-  // each copy is as long as the kernel before it.  Kernel time per piece on 2^26-scalar calls (tools/mul_kernel_times.sh,
+  // scalars per resident thread (16 for calls of 2^25 scalars and more), i.e. 196 608 x 1, 2, 4, 8 (16) scalars at three waves per SIMD
+  // (2^17 ... 2^20 (2^21) at two, which the measurements below were taken at) - each copy is as long as the kernel before it.  Kernel time per piece on 2^26-scalar calls (tools/mul_kernel_times.sh,
   // profiles/r04_mul_split.txt): 8 scalars per thread 0.888 ms = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s; 32 per
   // thread lose (round 4, first half: the parked sums of a piece no longer stay in the Infinity Cache: 604 MB at 2^22), and a long piece
   // lengthens the pipeline's fill and drain.  tools/ab_mul_sched.sh (profiles/r04_mul_sched.txt): this schedule 1222-1230 / 1261-1270 M

@@ -252,13 +252,19 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
+#ifndef ECL_MUL_FASTSUM
+#define ECL_MUL_FASTSUM 1  /* the low-register window sum (wtab_sum_fast, below) in k_mul_check; A/B: 0 = wtab_sum_xyzz (scalar in registers, per-lane states) */
+#endif
+__device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad);
 #ifndef ECL_MUL_RINGS
 #define ECL_MUL_RINGS 1  /* A/B: 0 = every hash finishes its filter test in place */
 #endif
 #define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 #ifndef ECL_MUL_WAVES
-#define ECL_MUL_WAVES 2  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side
-                            launches 65536 x ECL_MUL_WAVES threads per piece */
+#define ECL_MUL_WAVES 3  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side launches
+                            65536 x ECL_MUL_WAVES threads per piece.  With the low-register window sum the kernel fits 168 VGPRs (one spill): three
+                            waves hide the wait states between dependent multiply-adds better than two (profiles/r04_mul_fastsum.txt: 2^26-scalar
+                            calls 1391 against 1370 M scalars/s, 2^24 equal); the sum with the scalar in registers needed 67 spills there */
 #endif
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
@@ -276,6 +282,18 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
   for (u32 r = 0; r < R; ++r) {
     const u32 i = r * nt + t;
     if (i >= n) break;
+#if ECL_MUL_FASTSUM
+    u32 bad;
+    xyzz acc = wtab_sum_fast(k + (size_t)i * 8, gtab, bad);
+    acc.inf = 0;
+    if (__builtin_expect(bad || fe_is_zero(acc.ZZ), 0)) {  // a zero digit (stand-in point) or P = +-Q on the way: the complete sum
+      u32 kk[9];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kk[j] = k[(size_t)i * 8 + j];
+      kk[8] = 0;
+      acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
+    }
+#else
     u32 kk[9];
     const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
     kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
@@ -283,6 +301,7 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves ZZ = 0, and a zero in
     // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
     if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
+#endif
     infmask |= (acc.inf ? 1u : 0u) << r;
     fe tt, xs, ys, nprod;
     fe_mul_pair(tt, xs, acc.ZZ, acc.ZZZ, acc.X, acc.ZZZ);
