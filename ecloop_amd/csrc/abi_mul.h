@@ -304,7 +304,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
   a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
-  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_lazy, any width) is k*G for any
+  // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_fast, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
   // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4 and then 8
   // scalars per resident thread (16 for calls of 2^25 scalars and more), i.e. 196 608 x 1, 2, 4, 8 (16) scalars at three waves per SIMD

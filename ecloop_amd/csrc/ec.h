@@ -70,48 +70,15 @@ FE_FN jac jac_madd(const jac& p, const fe& qx, const fe& qy) {
   return r;
 }
 
-// ---- the window sums of `mul` (k_mul_check): the same two additions with lazy magnitudes and no exceptional cases -------
+// ---- the window sums of `mul` (k_mul_check): mixed additions with lazy magnitudes and no exceptional cases -------
 // A sum of table points b_w * 2^(W w) * G over distinct windows never meets P = +-Q on the way unless the scalar itself is
-// 0 (mod n) or crafted around n - and then h = 0 makes Z3 = Z1 * h = 0, which stays 0 through every later addition: the
-// caller tests Z ONCE at the end and sends such a scalar through the complete formulas above (wtab_sum), instead of
-// testing h in each of the 11 additions.  Magnitudes: X, Z in / out 1, Y in / out <= 3 (never normalised: it only ever
-// enters a subtraction that is normalised anyway, or a multiplication); three weak normalisations per addition (h, r, X3)
-// where jac_madd spends seven.  8M + 3S.
-FE_FN jac jac_madd_lazy(const jac& p, const fe& qx, const fe& qy) {
-  const fe zz = fe_sqr(p.Z);
-  const fe u2 = fe_mul(qx, zz);
-  const fe s2 = fe_mul(qy, fe_mul(zz, p.Z));
-  fe h = fe_sub(u2, p.X);                   // magnitude 3
-  fe_normalize_weak(h);
-  fe rr = fe_add(s2, fe_neg(p.Y, 3));       // magnitude 5
-  fe_normalize_weak(rr);
-  const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(p.X, hh);
-  jac r;
-  r.inf = 0;
-  r.X = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));  // rr^2 - hhh - 2v: magnitude 6
-  fe_normalize_weak(r.X);
-  r.Y = fe_add(fe_mul(rr, fe_sub(v, r.X)), fe_neg(fe_mul(p.Y, hhh), 1));       // magnitude 3
-  r.Z = fe_mul(p.Z, h);
-  return r;
-}
-// (px, py) + (qx, qy), both affine (Z1 = 1): 4M + 2S, the first addition of every window sum
-FE_FN jac jac_mmadd_lazy(const fe& px, const fe& py, const fe& qx, const fe& qy) {
-  fe h = fe_sub(qx, px), rr = fe_sub(qy, py);
-  fe_normalize_weak(h);
-  fe_normalize_weak(rr);
-  const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(px, hh);
-  jac r;
-  r.inf = 0;
-  r.X = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
-  fe_normalize_weak(r.X);
-  r.Y = fe_add(fe_mul(rr, fe_sub(v, r.X)), fe_neg(fe_mul(py, hhh), 1));
-  r.Z = h;
-  return r;
-}
-
-// The same two additions with Z^2 and Z^3 carried instead of Z ("XYZZ": x = X / ZZ, y = Y / ZZZ): the squaring of Z that opens
-// every Jacobian mixed addition goes away - 8M + 2S per table point instead of 8M + 3S - and the affine + affine start hands over
-// hh, hhh as they are.  Magnitudes as above (X, ZZ, ZZZ in / out 1, Y <= 3); h = 0 on the way leaves ZZ = ZZZ = 0 for good.
+// 0 (mod n) or crafted around n - and then h = 0 makes ZZ3 = ZZ1 * h^2 = 0, which stays 0 through every later addition: the
+// caller tests ZZ ONCE at the end and sends such a scalar through the complete formulas above (wtab_sum), instead of
+// testing h in each of the additions.  Y is never normalised (it only ever enters a subtraction that is normalised anyway,
+// or a multiplication); three weak normalisations per addition (h, r, X3) where jac_madd spends seven.
+// Z^2 and Z^3 are carried instead of Z ("XYZZ": x = X / ZZ, y = Y / ZZZ): the squaring of Z that opens every Jacobian mixed
+// addition goes away - 8M + 2S per table point instead of 8M + 3S - and the affine + affine start (4M + 2S) hands over hh, hhh
+// as they are.  Magnitudes: X, ZZ, ZZZ in / out 1, Y in / out <= 3; h = 0 on the way leaves ZZ = ZZZ = 0 for good.
 struct xyzz {
   fe X, Y, ZZ, ZZZ;
   u32 inf;

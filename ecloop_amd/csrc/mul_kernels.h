@@ -109,51 +109,12 @@ __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
   }
   return acc;
 }
-#ifndef ECL_MUL_MMADD
-#define ECL_MUL_MMADD 1  /* A/B: 0 = the second point goes through the general mixed addition too (one code body less) */
-#endif
 // the complete sum out of line: the fallback of a scalar whose lazy sum ended with Z = 0 (never taken by a random scalar)
 __device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { return wtab_sum(kk, t); }
-// The same sum for k_mul_check's hot loop: lazy additions without exceptional cases (ec.h: jac_madd_lazy; the caller tests Z once
-// at the end), the second point of a sum added to the first as affine + affine (4M + 2S instead of 8M + 3S).  State: npts = 0
-// nothing yet, 1 = one table point held as it is (acc.X, acc.Y), >= 2 = Jacobian.  Returns with acc.inf = 1 for an all-zero scalar
-// and acc.Z = 1 for a single point.
-__device__ __forceinline__ jac wtab_sum_lazy(const u32 kk[9], const wtab t) {
-  jac acc;
-  acc.X = fe_zero(), acc.Y = fe_zero(), acc.Z = fe_one(), acc.inf = 1;
-  u32 npts = 0, carry = 0, nneg = 0;
-  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  u32 dnext = wtab_recode(t, 0, wtab_digit(kk, t, 0), carry, nneg);
-  if (dnext) {
-    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
-    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-  }
-#pragma unroll 1
-  for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = dnext, neg = nneg;
-    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    dnext = w + 1 < t.nwin ? wtab_recode(t, w + 1, wtab_digit(kk, t, w + 1), carry, nneg) : 0u;
-    if (dnext) {
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.stride + dnext - 1) * 16);
-      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-    }
-    if (!digit) continue;
-    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-    const fe qx = fe_from_words(xw), qy = fe_cneg_weak(fe_from_words(yw), neg);
-    if (npts == 0) acc.X = qx, acc.Y = qy, acc.inf = 0;
-#if ECL_MUL_MMADD
-    else if (npts == 1) acc = jac_mmadd_lazy(acc.X, acc.Y, qx, qy);
-#endif
-    else acc = jac_madd_lazy(acc, qx, qy);
-    ++npts;
-  }
-  return acc;
-}
-#ifndef ECL_MUL_XYZZ
-#define ECL_MUL_XYZZ 1  /* A/B: 0 = Jacobian window sums (8M + 3S per table point, round 4's first form) */
-#endif
-// ... and with Z^2, Z^3 carried instead of Z (ec.h: xyzz_madd_lazy, 8M + 2S per table point).  Same states; a single point returns
-// with ZZ = ZZZ = 1.
+// The sum for k_mul_check's hot loop: lazy additions without exceptional cases, Z^2 and Z^3 carried instead of Z (ec.h: xyzz_madd_lazy,
+// 8M + 2S per table point; the caller tests ZZ once at the end), the second point of a sum added to the first as affine + affine (4M + 2S).
+// State: npts = 0 nothing yet, 1 = one table point held as it is (acc.X, acc.Y), >= 2 = XYZZ.  Returns with acc.inf = 1 for an all-zero
+// scalar and ZZ = ZZZ = 1 for a single point.  (The scalar-in-registers form; the kernel ships with wtab_sum_fast below.)
 __device__ __forceinline__ xyzz wtab_sum_xyzz(const u32 kk[9], const wtab t) {
   xyzz acc;
   acc.X = fe_zero(), acc.Y = fe_zero(), acc.ZZ = fe_one(), acc.ZZZ = fe_one(), acc.inf = 1;
@@ -269,14 +230,13 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
-#if ECL_MUL_RINGS && ECL_MUL_XYZZ
+#if ECL_MUL_RINGS
   __shared__ u32 q_mem[4][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave (add_kernel.h)
 #endif
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt) return;  // nt is a multiple of 256: whole workgroups leave
   fe prod = fe_one();
   u32 infmask = 0;
-#if ECL_MUL_XYZZ
   // parked per scalar: X * ZZZ, Y * ZZ, T = ZZ * ZZZ and the running product of the T's; x = X ZZZ / T, y = Y ZZ / T
 #pragma unroll 1
   for (u32 r = 0; r < R; ++r) {
@@ -357,48 +317,6 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     inv = fe_mul(inv, T);
     if ((infmask >> r) & 1u) continue;
     const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
-    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
-  }
-#endif
-#else
-#pragma unroll 1
-  for (u32 r = 0; r < R; ++r) {
-    const u32 i = r * nt + t;
-    if (i >= n) break;
-    u32 kk[9];
-    const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
-    kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
-    jac acc = wtab_sum_lazy(kk, gtab);
-    // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves Z = 0, and a zero in
-    // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
-    if (!acc.inf && __builtin_expect(fe_is_zero(acc.Z), 0)) acc = wtab_sum_complete(kk, gtab);
-    const fe z = acc.inf ? fe_one() : acc.Z;
-    infmask |= (acc.inf ? 1u : 0u) << r;
-    u32* p = tmp + (size_t)r * 36 * nt + t;
-#pragma unroll
-    for (int l = 0; l < FE_LIMBS; ++l) {
-      p[(size_t)l * nt] = acc.X.n[l], p[(size_t)(9 + l) * nt] = acc.Y.n[l];
-      p[(size_t)(18 + l) * nt] = z.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
-    }
-    prod = fe_mul(prod, z);
-  }
-  fe inv = fe_inv(prod);
-#pragma unroll 1
-  for (u32 r = R; r-- > 0;) {
-    const u32 i = r * nt + t;
-    if (i >= n) continue;
-    const u32* p = tmp + (size_t)r * 36 * nt + t;
-    fe X, Y, Z, pre;
-#pragma unroll
-    for (int l = 0; l < FE_LIMBS; ++l) {
-      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
-      Z.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
-    }
-    const fe zi = fe_mul(inv, pre);
-    inv = fe_mul(inv, Z);
-    if ((infmask >> r) & 1u) continue;
-    const fe zi2 = fe_sqr(zi);
-    const fe x = fe_mul(X, zi2), y = fe_mul(Y, fe_mul(zi2, zi));
     check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
   }
 #endif
