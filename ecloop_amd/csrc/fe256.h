@@ -298,6 +298,7 @@ FE_FN fe fe_sqr(const fe& a) {
 // independent multiply-add to issue: same instructions, no padding.  Used where a kernel runs at two waves per SIMD and has the
 // independent pairs at hand (`mul`: ec.h, xyzz_madd_lazy).
 FE_FN void fe_mul2(fe& r1, fe& r2, const fe& a1, const fe& b1, const fe& a2, const fe& b2) {
+  fe o1, o2;  // the results may alias the operands: written at the end
   u64 c1 = 0, d1 = 0, c2 = 0, d2 = 0;
   const u32 R1 = fe_opaque(FE_R1);
 #pragma unroll
@@ -331,20 +332,22 @@ FE_FN void fe_mul2(fe& r1, fe& r2, const fe& a1, const fe& b1, const fe& a2, con
     c1 += (u64)u1 * FE_R0;
     FE_PIN64(c2);
     c2 += (u64)u2 * FE_R0;
-    r1.n[k] = (u32)c1 & FE_M, r2.n[k] = (u32)c2 & FE_M;
+    o1.n[k] = (u32)c1 & FE_M, o2.n[k] = (u32)c2 & FE_M;
     c1 >>= 29, c2 >>= 29;
     FE_PIN64(c1);
     c1 += (u64)u1 * R1;
     FE_PIN64(c2);
     c2 += (u64)u2 * R1;
   }
-  fe_mul_tail(r1, c1, d1, t81);
-  fe_mul_tail(r2, c2, d2, t82);
+  fe_mul_tail(o1, c1, d1, t81);
+  fe_mul_tail(o2, c2, d2, t82);
+  r1 = o1, r2 = o2;
 }
 FE_FN void fe_sqr2(fe& r1, fe& r2, const fe& a1, const fe& a2) {
   u32 x1[9], x2[9];  // doubled operands
 #pragma unroll
   for (int i = 0; i < 9; ++i) x1[i] = a1.n[i] * 2, x2[i] = a2.n[i] * 2;
+  fe o1, o2;  // the results may alias the operands: written at the end
   u64 c1 = 0, d1 = 0, c2 = 0, d2 = 0;
   const u32 R1 = fe_opaque(FE_R1);
 #define FE_SQ2_COL(acc1, acc2, k)                                            \
@@ -373,7 +376,7 @@ FE_FN void fe_sqr2(fe& r1, fe& r2, const fe& a1, const fe& a2) {
     c1 += (u64)u1 * FE_R0;
     FE_PIN64(c2);
     c2 += (u64)u2 * FE_R0;
-    r1.n[k] = (u32)c1 & FE_M, r2.n[k] = (u32)c2 & FE_M;
+    o1.n[k] = (u32)c1 & FE_M, o2.n[k] = (u32)c2 & FE_M;
     c1 >>= 29, c2 >>= 29;
     FE_PIN64(c1);
     c1 += (u64)u1 * R1;
@@ -381,8 +384,9 @@ FE_FN void fe_sqr2(fe& r1, fe& r2, const fe& a1, const fe& a2) {
     c2 += (u64)u2 * R1;
   }
 #undef FE_SQ2_COL
-  fe_mul_tail(r1, c1, d1, t81);
-  fe_mul_tail(r2, c2, d2, t82);
+  fe_mul_tail(o1, c1, d1, t81);
+  fe_mul_tail(o2, c2, d2, t82);
+  r1 = o1, r2 = o2;
 }
 
 __host__ __device__ __noinline__ inline fe fe_sqr_n(fe a, int n) {

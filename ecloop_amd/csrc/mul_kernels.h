@@ -213,6 +213,9 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
+#ifndef ECL_MUL_LOOP_PAIRS
+#define ECL_MUL_LOOP_PAIRS 1  /* the additions inside wtab_sum_fast's loop as interleaved pairs too (+0.5-1 % on 2^24-scalar calls); A/B: 0 */
+#endif
 #ifndef ECL_MUL_FASTSUM
 #define ECL_MUL_FASTSUM 1  /* the low-register window sum (wtab_sum_fast, below) in k_mul_check; A/B: 0 = wtab_sum_xyzz (scalar in registers, per-lane states) */
 #endif
@@ -363,7 +366,13 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     const bool more = w + 1u < t.nwin;
     const u32 neg = sn;
     dn = more ? wtab_recode(t, w + 1u, wtab_digit_mem(kw, t, w + 1u), carry, sn) : 1u;
+#if ECL_MUL_LOOP_PAIRS
+    fe u2, s2p;
+    fe_mul_pair(u2, s2p, fe_from_words(xw), acc.ZZ, fe_from_words(yw), acc.ZZZ);
+    const fe s2m = fe_neg(s2p, 1);
+#else
     const fe u2 = fe_mul(fe_from_words(xw), acc.ZZ), s2p = fe_mul(fe_from_words(yw), acc.ZZZ), s2m = fe_neg(s2p, 1);
+#endif
     if (more) {
       bad |= dn == 0u;
       dn = dn ? dn : 1u;
@@ -377,6 +386,17 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     fe_normalize_weak(h);
     fe rr = fe_add(s2, fe_neg(acc.Y, 3));
     fe_normalize_weak(rr);
+#if ECL_MUL_LOOP_PAIRS
+    fe hh, rr2, hhh, v, t1, t2;
+    fe_sqr_pair(hh, rr2, h, rr);
+    fe_mul_pair(hhh, v, hh, h, acc.X, hh);
+    fe X3 = fe_add(fe_add(rr2, fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
+    fe_normalize_weak(X3);
+    fe_mul_pair(t1, t2, rr, fe_sub(v, X3), acc.Y, hhh);
+    acc.Y = fe_add(t1, fe_neg(t2, 1));
+    acc.X = X3;
+    fe_mul_pair(acc.ZZ, acc.ZZZ, acc.ZZ, hh, acc.ZZZ, hhh);
+#else
     const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(acc.X, hh);
     fe X3 = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
     fe_normalize_weak(X3);
@@ -384,6 +404,7 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     acc.X = X3;
     acc.ZZ = fe_mul(acc.ZZ, hh);
     acc.ZZZ = fe_mul(acc.ZZZ, hhh);
+#endif
   }
   return acc;
 }

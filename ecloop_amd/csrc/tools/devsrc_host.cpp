@@ -41,6 +41,18 @@ void dh_fe_op(int op, uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
   case 10: z = fe_inv_divsteps(x); break;
   case 11: z = fe_inv_fermat(x); break;
   case 12: z = fe_inv_divsteps(fe_add(fe_neg(fe_add(x, x), 2), fe_add(fe_add(y, y), fe_add(y, y)))); break;  // 1 / (4y - 2x), magnitude 7 in
+  case 13: {  // the interleaved pair: (x y, y^2... ) with results aliasing operands; returns x*y + (x+y)^2's partner checked separately
+    fe u = x, v = y;
+    fe_mul2(u, v, u, y, v, x);  // u = x y, v = y x (aliased)
+    z = fe_add(u, v);           // 2 x y
+    break;
+  }
+  case 14: {
+    fe u = x, v = y;
+    fe_sqr2(u, v, u, v);        // aliased
+    z = fe_add(u, v);           // x^2 + y^2
+    break;
+  }
   default: z = fe_zero();
   }
   st(r, z);

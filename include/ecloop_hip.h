@@ -85,7 +85,10 @@ int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 int ecl_hip_pin_host(const void *p, size_t bytes);
 int ecl_hip_unpin_host(const void *p);
 /* ... or get page-locked host memory to begin with (hipHostMalloc / hipHostFree): scalar arrays given to
-   ecl_hip_mul_batch from such memory are read by the GPU's copy engine directly, without the staging copy. */
+   ecl_hip_mul_batch from such memory are read by the GPU's copy engine directly, without the staging copy.  Prefer this
+   for large arrays on a two-socket host: the runtime places the pages next to the GPU, whereas a buffer registered in
+   place (ecl_hip_pin_host) stays where its pages were first touched - from the far socket the copy runs at about half
+   the rate (30 against 57 GB/s measured: 0.93 instead of 1.3 G scalars/s for `mul`). */
 void *ecl_hip_alloc_host(size_t bytes);
 void ecl_hip_free_host(void *p);
 

@@ -47,6 +47,9 @@ def test_field(D):
             assert D.dh_parity(orc.fe(a), orc.fe(b)) == ((2 * a - b) % P) & 1
         assert op(1, a) == a * a % P
         assert op(5, a) == (-a) % P
+        for b in vals[:6]:  # the interleaved pairs (fe_mul2 / fe_sqr2), results aliasing their operands
+            assert op(13, a, b) == 2 * a * b % P
+            assert op(14, a, b) == (a * a + b * b) % P
     for a in vals[1:40]:
         assert op(2, a) == pow(a, P - 2, P)
 
