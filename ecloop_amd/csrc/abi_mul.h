@@ -306,20 +306,21 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_fast, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4 and then 8
-  // scalars per resident thread (16 for calls of 2^25 scalars and more), i.e. 196 608 x 1, 2, 4, 8 (16) scalars at three waves per SIMD
-  // (2^17 ... 2^20 (2^21) at two, which the measurements below were taken at) - each copy is as long as the kernel before it.  Kernel time per piece on 2^26-scalar calls (tools/mul_kernel_times.sh,
-  // profiles/r04_mul_split.txt): 8 scalars per thread 0.888 ms = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s; 32 per
-  // thread lose (round 4, first half: the parked sums of a piece no longer stay in the Infinity Cache: 604 MB at 2^22), and a long piece
-  // lengthens the pipeline's fill and drain.  tools/ab_mul_sched.sh (profiles/r04_mul_sched.txt): this schedule 1222-1230 / 1261-1270 M
-  // scalars/s on 2^24 / 2^26-scalar calls, a first piece of 2^18 followed at once by full pieces (round 3's) 1214 / 1253, top pieces of 16
-  // per thread on 2^24-scalar calls 1187; two staging buffers instead of four 1208 / 1249.
+  // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4, 8 and then 10
+  // scalars per resident thread (12 for calls of 2^26 scalars and more), i.e. 196 608 x 1, 2, 4, 8, 10 (12) scalars at three waves per SIMD -
+  // each copy is about as long as the kernel before it.  More scalars per thread share an inversion among more of them but park more sums
+  // (144 bytes each: at 16 per thread a piece parks 453 MB, past the Infinity Cache) and lengthen the pipeline's fill and drain:
+  // tools/ab_mul_topr.sh (profiles/r04_mul_sched.txt, three waves per SIMD): 2^24-scalar calls 1252 / 1277 / 1252 / 1199 M scalars/s at
+  // 8 / 10 / 12 / 16 per thread, 2^25: 1313 / 1320 / 1319 / 1291, 2^26: 1354 / 1330 / 1346 / 1324, 2^27: 1368 / 1367 / 1378 / 1340.
+  // Round 4's earlier measurements at two waves per SIMD (tools/mul_kernel_times.sh, profiles/r04_mul_split.txt): 8 per thread 0.888 ms per
+  // piece = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s, 32 per thread lose; doubling first pieces 1222-1230 / 1261-1270
+  // on 2^24 / 2^26-scalar calls against 1214 / 1253 for a 2^18-scalar piece followed at once by full ones; two staging buffers 1208 / 1249.
   // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
   static const u32 first_R = getenv("ECL_HIP_MUL_FIRST_R") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST_R")) : 1u;   // tuning hooks (A/B runs)
   static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 200u;
   static const u32 top_R = getenv("ECL_HIP_MUL_TOP_R") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP_R")) : 0u;
   const u64 unit = (u64)mul_nt_target() * mul_chains_per_thread();
-  const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 25) ? 16u : 8u));
+  const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 26) ? 12u : 10u));
   const u32 top = h->kbuf_cap < top_want ? h->kbuf_cap : (u32)top_want;
   u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
