@@ -1,0 +1,23 @@
+"""The A/B switches kept in the device source (-DECL_* : the alternatives DESIGN.md's measurements were taken against - the two-kernel
+form of `mul`, the scalar-in-registers window sum, operations one by one instead of in pairs, filter tests in place, the addition-chain
+inversion, unpacked matrix rows of the division steps) must keep compiling: a syntax-only pass of hipcc over the library's translation
+unit with all of them flipped (seconds, no code generation).  Skipped without hipcc."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLIPPED = ["-DECL_MUL_SPLIT=1", "-DECL_MUL_SUM_FAST=0", "-DECL_MUL_FASTSUM=0", "-DECL_MUL_PAIRS=0", "-DECL_MUL_LOOP_PAIRS=0", "-DECL_MUL_RINGS=0",
+           "-DECL_FE_INV_DIVSTEPS=0", "-DECL_DS_PACKED=0", "-DMUL_NBUF=2"]
+
+
+@pytest.mark.parametrize("flags", [FLIPPED, ["-DECL_MUL_SPLIT=1", "-DECL_MUL_SUM_WAVES=3", "-DECL_MUL_FIN_WAVES=3"]], ids=["all-flipped", "two-kernel-3-waves"])
+def test_alternative_builds_still_compile(flags):
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if not hipcc:
+        pytest.skip("no hipcc")
+    pr = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only"] + flags + [os.path.join(ROOT, "ecloop_amd", "csrc", "ecloop_hip.hip")],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd="/tmp")
+    assert pr.returncode == 0 and b"error" not in pr.stderr, pr.stderr.decode(errors="replace")[-3000:]
