@@ -531,7 +531,7 @@ def bench_add(args, sync, dev_index, emit, t_process):
         kernel_ms, launches, kkeys = ks.dev.timing()
         setup_ms, setups = ks.dev.setup_timing()
         total = (nkeys if mode == "strong" else nkeys * world) * steps
-        shards = sync.gather({"gpu": dev_index, "worker": rank, "first_key": hex(start), "keys_per_step": cnt,
+        shards = sync.gather({"gpu": dev_index, "worker": rank, "first_key": hex(start), "keys_per_step": cnt, "lanes": ks.dev.geometry()[1],
                               "ms_per_step": round(mine_dt / steps * 1e3, 3), "kernel_ms_per_step": round(kernel_ms / steps, 3),
                               "found_per_step": len(ks.found), "planted_checked": len(mine)})
         return {"dt": dt, "value": total / dt / 1e6, "ms_per_step": dt / steps * 1e3, "kernel_ms": kernel_ms, "launches": launches,

@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window", "ecl_hip_fetch_found",
 ]
 
 _lib = None
@@ -56,6 +56,7 @@ def load():
     lib.ecl_hip_reserve.argtypes = [P, C.c_uint64, C.c_uint32]
     lib.ecl_hip_add_range.argtypes = [P, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_mul_batch.argtypes = [P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.ecl_hip_fetch_found.argtypes = [P, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ecl_hip_bloom_insert.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_get_bloom.argtypes = [P, C.c_void_p, C.c_uint64]
     lib.ecl_hip_bloom_insert_count.argtypes = [P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -177,6 +178,14 @@ class Device:
         rc = self.lib.ecl_hip_add_range(self.h, s.ctypes.data, nkeys, out.ctypes.data, cap, C.byref(n))
         self._chk(rc, allow=(E_OVERFLOW,))
         return out[: min(n.value, cap)], n.value
+
+    def fetch_found(self, first, n):
+        """records [first, first + n) of the last add_range / mul_batch call that are still on the device (after an overflow:
+        the call itself delivered [0, cap)); fewer come back only if the call produced more than the device kept"""
+        out = np.zeros(n, dtype=FOUND_DTYPE)
+        got = C.c_uint32()
+        self._chk(self.lib.ecl_hip_fetch_found(self.h, first, out.ctypes.data, n, C.byref(got)))
+        return out[: got.value]
 
     def mul_batch(self, scalars, cap=4096):
         k = limbs_array(scalars)

@@ -28,10 +28,6 @@ static int ensure_gtable(ecl_hip* h) {
 // device that uses the width (the host program runs two per GPU), freed with the last of them.  Before a table is handed
 // out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
 // are compared with the double-and-add kernel.
-#ifndef ECL_MUL_SPLIT
-#define ECL_MUL_SPLIT 0  /* 1: k_mul_sum + k_mul_finish instead of k_mul_check (measured equal: profiles/r04_mul_split.txt) */
-#endif
-#define MUL_CMAX 4u  /* at most this many chains per summing thread (two-kernel form) */
 #define MUL_W_MIN 8u
 #define MUL_W_MAX 26u
 #define MUL_W_START 22u               /* 11 rows x 2^21 points (signed digits), 1.5 GB */
@@ -154,23 +150,27 @@ extern "C" int ecl_hip_get_mul_window(ecl_hip* h, uint32_t* bits) {
   return ECL_OK;
 }
 
-// what a mul_batch of n scalars needs before its first copy: the window table of the width in force, the copy stream and
-// its events, the device staging for one chunk (x2: the copy engine runs one chunk ahead of the kernel) and the parking
-// space of one chunk - sized to the call, grown on demand
+// what a mul_batch of n scalars needs before its first copy: the window table of the width in force, the copy stream, the second
+// compute stream and the events, the device staging (MUL_NBUF buffers: the copy engine runs ahead of the kernels) and the parking
+// space of two pieces in flight - sized to the call, grown on demand
 static int mul_setup(ecl_hip* h, u32 n, u32 W) {
   int rc;
   if ((rc = ensure_multable(h, W)) != ECL_OK) return rc;
   if (!h->copy_stream) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (int i = 0; i < MUL_NBUF; ++i) {
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
     }
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   }
   u32 want = 1u << 16;
   while (want < MUL_CHUNK && want < n) want <<= 1;
   if (want > h->kbuf_cap) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream2));
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     for (int i = 0; i < MUL_NBUF; ++i) {
       if (h->d_kbuf[i]) HIPCHK(h, hipFree(h->d_kbuf[i]));
@@ -178,64 +178,51 @@ static int mul_setup(ecl_hip* h, u32 n, u32 W) {
       h->d_kbuf[i] = nullptr, h->pin_k[i] = nullptr;
     }
     h->pin_cap = 0;
-    if (h->d_multmp) HIPCHK(h, hipFree(h->d_multmp));
-    h->d_multmp = nullptr, h->kbuf_cap = 0;
+    for (int i = 0; i < 2; ++i) {
+      if (h->d_multmp[i]) HIPCHK(h, hipFree(h->d_multmp[i]));
+      h->d_multmp[i] = nullptr;
+    }
+    h->kbuf_cap = 0;
     for (int i = 0; i < MUL_NBUF; ++i) HIPCHK(h, hipMalloc(&h->d_kbuf[i], (size_t)want * 32));
     // the kernel indexes the planes as r * 36 * nt + plane * nt + t with nt = ceil(m / R) rounded up to whole workgroups:
-    // up to R * 256 * C slots more than m (C <= MUL_CMAX chains per summing thread)
-    // (+ 10 words per thread behind the planes: the chain products and infinity masks that k_mul_sum hands to k_mul_finish)
-    HIPCHK(h, hipMalloc(&h->d_multmp, (((size_t)want + MUL_R * 256u * MUL_CMAX) * 36 + ((size_t)want + 256u * MUL_CMAX) * 10) * sizeof(u32)));
+    // up to R * 256 slots more than m
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipMalloc(&h->d_multmp[i], ((size_t)want + MUL_R * 256u) * 36 * sizeof(u32)));
     h->kbuf_cap = want;
   }
   return ECL_OK;
+}
+// (the tuning hooks of this file read the environment of whoever loaded the library: every value is clamped to what the piece loop
+//  can run with - a zero or tiny thread count divided by zero / never advanced the loop, advisor r04)
+static u32 env_u32(const char* name, u32 dflt, u32 lo, u32 hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  const long v = atol(e);
+  return v < (long)lo ? lo : (v > (long)hi ? hi : (u32)v);
 }
 // threads and scalars per thread of one k_mul_check launch over m scalars: as many scalars per thread (one shared inversion, at most
 // MUL_R) as still keep 65536 x ECL_MUL_WAVES threads in flight - what the chip holds at once; a few blocks more would wait for a whole
 // round - in whole workgroups, so that every row of scalars and every parking plane starts on a 1 KiB boundary
 static u32 mul_nt_target() {
-  static const u32 v = getenv("ECL_HIP_MUL_NT") ? (u32)atoi(getenv("ECL_HIP_MUL_NT")) : 65536u * (ECL_MUL_SPLIT ? ECL_MUL_SUM_WAVES : ECL_MUL_WAVES);  // tuning hook (A/B runs)
+  static const u32 v = env_u32("ECL_HIP_MUL_NT", 65536u * ECL_MUL_WAVES, 1024u, 1u << 22) & ~255u;  // tuning hook (A/B runs)
   return v;
 }
-// chains per summing thread (two-kernel form): the finishing kernel (hash-bound, 120 VGPRs) may hold more waves per SIMD than the summing
-// kernel; a piece is then cut into as many chains as the finishing kernel has lanes and the summing threads take several each
-static u32 mul_chains_per_thread() {
-#if ECL_MUL_SPLIT
-  static_assert(ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES >= 1 && ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES <= (int)MUL_CMAX, "chains per summing thread");
-  static const u32 C = getenv("ECL_HIP_MUL_CHAINS") && atoi(getenv("ECL_HIP_MUL_CHAINS")) >= 1 && atoi(getenv("ECL_HIP_MUL_CHAINS")) <= (int)MUL_CMAX
-                           ? (u32)atoi(getenv("ECL_HIP_MUL_CHAINS")) : (u32)(ECL_MUL_FIN_WAVES / ECL_MUL_SUM_WAVES);
-  return C;
-#else
-  return 1u;
-#endif
-}
-static void mul_geometry(u32 m, u32 C, u32* R_out, u32* nt_out) {
-  const u32 chains = mul_nt_target() * C;
+static void mul_geometry(u32 m, u32* R_out, u32* nt_out) {
+  const u32 chains = mul_nt_target();
   u32 R = (m + chains - 1) / chains;
   R = R < 1 ? 1 : (R > MUL_R ? MUL_R : R);
-  const u32 unit = 256u * C;
-  *R_out = R, *nt_out = ((m + R - 1) / R + unit - 1u) / unit * unit;
+  *R_out = R, *nt_out = ((m + R - 1) / R + 255u) / 256u * 256u;
 }
-// one piece: the window sums, then inversion + hashing (two kernels: ECL_MUL_SPLIT) or all of it in k_mul_check
-static void mul_launch_piece(ecl_hip* h, const u32* d_k, u32 m, u32 at, const wtab& gtab, const add_args& a) {
+// one piece on compute stream `lane` (0: the context's stream, 1: the second one), parking space `lane`
+static void mul_launch_piece(ecl_hip* h, int lane, const u32* d_k, u32 m, u32 at, const wtab& gtab, const add_args& a) {
   u32 R, nt;
   const bool a33 = h->flags & ECL_ADDR33, a65 = h->flags & ECL_ADDR65;
-#if ECL_MUL_SPLIT
-  const u32 C = mul_chains_per_thread();
-  mul_geometry(m, C, &R, &nt);
-  u32* chain = h->d_multmp + ((size_t)h->kbuf_cap + MUL_R * 256u * MUL_CMAX) * 36;
-  dim3 blk(256);
-  hipLaunchKernelGGL(k_mul_sum, dim3((nt / C + 255u) / 256u), blk, 0, h->stream, d_k, m, gtab, h->d_multmp, chain, nt, R, C);
-  dim3 grid(nt / 256);
-  if (a33 && a65) hipLaunchKernelGGL((k_mul_finish<true, true>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
-  else if (a33) hipLaunchKernelGGL((k_mul_finish<true, false>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
-  else hipLaunchKernelGGL((k_mul_finish<false, true>), grid, blk, 0, h->stream, m, at, a, h->d_multmp, chain, nt, R);
-#else
-  mul_geometry(m, 1, &R, &nt);
+  hipStream_t st = lane ? h->stream2 : h->stream;
+  u32* tmp = h->d_multmp[lane];
+  mul_geometry(m, &R, &nt);
   dim3 grid(nt / 256), blk(256);
-  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
-  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
-  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, h->stream, d_k, m, at, gtab, a, h->d_multmp, nt, R);
-#endif
+  if (a33 && a65) hipLaunchKernelGGL((k_mul_check<true, true>), grid, blk, 0, st, d_k, m, at, gtab, a, tmp, nt, R);
+  else if (a33) hipLaunchKernelGGL((k_mul_check<true, false>), grid, blk, 0, st, d_k, m, at, gtab, a, tmp, nt, R);
+  else hipLaunchKernelGGL((k_mul_check<false, true>), grid, blk, 0, st, d_k, m, at, gtab, a, tmp, nt, R);
 }
 // window width of the next call: the caller's, or the short table until this context has seen enough scalars to pay for the long one
 static u32 mul_window_for(const ecl_hip* h, u32 n) {
@@ -259,7 +246,7 @@ extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
   if (!h || n == 0) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
-  if ((rc = ensure_found(h, raw_cap_of(h, cap ? cap : 1) + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, found_words_of(h, raw_cap_of(h, cap ? cap : 1)))) != ECL_OK) return rc;
   u32 W;
   return mul_setup_auto(h, n, &W);
 }
@@ -273,7 +260,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
-  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
   u32 W;
   if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
@@ -316,27 +303,40 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   // piece = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s, 32 per thread lose; doubling first pieces 1222-1230 / 1261-1270
   // on 2^24 / 2^26-scalar calls against 1214 / 1253 for a 2^18-scalar piece followed at once by full ones; two staging buffers 1208 / 1249.
   // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
-  static const u32 first_R = getenv("ECL_HIP_MUL_FIRST_R") ? (u32)atoi(getenv("ECL_HIP_MUL_FIRST_R")) : 1u;   // tuning hooks (A/B runs)
-  static const u32 grow_pct = getenv("ECL_HIP_MUL_GROW") ? (u32)atoi(getenv("ECL_HIP_MUL_GROW")) : 200u;
-  static const u32 top_R = getenv("ECL_HIP_MUL_TOP_R") ? (u32)atoi(getenv("ECL_HIP_MUL_TOP_R")) : 0u;
-  const u64 unit = (u64)mul_nt_target() * mul_chains_per_thread();
+  // Round 5: the pieces alternate between TWO compute streams (each with its own parking space).  A piece's 768 workgroups are all
+  // resident at once and do the same work, but they do not end together; on one stream the next piece's first workgroup waits for the
+  // last of this one.  On two streams the next piece's workgroups move into the slots as they fall free (ECL_HIP_MUL_STREAMS=1: one stream).
+  static const u32 first_R = env_u32("ECL_HIP_MUL_FIRST_R", 1u, 1u, MUL_R);   // tuning hooks (A/B runs)
+  static const u32 grow_pct = env_u32("ECL_HIP_MUL_GROW", 200u, 100u, 1600u);
+  static const u32 top_R = env_u32("ECL_HIP_MUL_TOP_R", 0u, 0u, MUL_R);
+  static const u32 nstreams = env_u32("ECL_HIP_MUL_STREAMS", 2u, 1u, 2u);
+  const u64 unit = (u64)mul_nt_target();
   const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 26) ? 12u : 10u));
   const u32 top = h->kbuf_cap < top_want ? h->kbuf_cap : (u32)top_want;
   u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // the second stream starts behind the counters' reset (and behind the call before)
+  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
   for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
     const u32 b = c % MUL_NBUF;
+    const int lane = (int)(c % nstreams);
+    hipStream_t st = lane ? h->stream2 : h->stream;
     m = n - at < lim ? n - at : lim;
+    // no crumb at the end: what would be left after this piece is taken along if it is less than half a piece (a 2^24-scalar call used to
+    // end on a 65 536-scalar launch - a third of the chip, one inversion per scalar - that took 0.10 ms, 0.8 % of the call)
+    if (n - at - m < lim / 2 && n - at <= h->kbuf_cap && (u64)(n - at) <= unit * MUL_R) m = n - at;
     if (c >= MUL_NBUF) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel MUL_NBUF pieces back is done with this buffer (and its staging twin)
     const void* src = scalars[at];
     if (!direct) memcpy(h->pin_k[b], scalars[at], (size_t)m * 32), src = h->pin_k[b];
     HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-    mul_launch_piece(h, h->d_kbuf[b], m, at, gtab, a);
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_copied[b], 0));
+    mul_launch_piece(h, lane, h->d_kbuf[b], m, at, gtab, a);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev_free[b], h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_free[b], st));
   }
+  HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));  // the context's stream goes on (list confirm, counters) when both are done
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;
   rc = collect_found(h, cap, rcap, out, &cnt, false);
@@ -361,7 +361,7 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
-  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
   u32 W;
   if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
@@ -401,7 +401,7 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
   hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
-  mul_launch_piece(h, h->d_kbuf[0], n, 0u, gtab, a);
+  mul_launch_piece(h, 0, h->d_kbuf[0], n, 0u, gtab, a);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,18 +43,21 @@ struct ecl_hip {
   // `mul`: scalars travel in pieces through MUL_NBUF device buffers (and as many pinned staging buffers for pageable callers), the copy
   // engine running up to MUL_NBUF - 1 pieces ahead of the kernel
   u32* d_kbuf[MUL_NBUF] = {}; u32* pin_k[MUL_NBUF] = {}; u32 kbuf_cap = 0, pin_cap = 0;
-  u32* d_multmp = nullptr;                     // parked Jacobian sums of one chunk (144 bytes per scalar)
+  u32* d_multmp[2] = {};                       // parked window sums of one piece (144 bytes per scalar), one space per compute stream
   const u32* d_multab = nullptr; u32 multab_W = 0;  // `mul`'s window table in use: one per (device, width), shared by the contexts
   u32 mul_W_fixed = 0;                         // ecl_hip_set_mul_window: 0 = automatic
   uint64_t mul_seen = 0;                       // scalars this context has multiplied (never reset: the automatic width goes by it)
   bool mul_long_failed = false;                // the long table could not be allocated: do not try again
   void* d_ver = nullptr; u32 ver_cap = 0;      // staging of ecl_hip_verify
   u32* d_rawtext = nullptr; size_t rawtext_cap = 0; u64* d_rawlines = nullptr; u32 rawlines_cap = 0;  // `mul -raw`: text and line table of one call
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_copied[MUL_NBUF] = {}, ev_free[MUL_NBUF] = {};
+  hipStream_t copy_stream = nullptr, stream2 = nullptr;  // `mul`: the copy engine's stream; the second compute stream (pieces alternate)
+  hipEvent_t ev_copied[MUL_NBUF] = {}, ev_free[MUL_NBUF] = {}, ev_fork = nullptr, ev_join = nullptr;
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
   u32* d_counter = nullptr;
+  // records of the last add_range / mul_batch call that are still on the device (ecl_hip_fetch_found): where they start in d_found,
+  // how many the device holds, the call's total, and whether the endo byte is meaningful
+  u32 last_at = 0, last_held = 0, last_total = 0; bool last_endo = false;
   // walk state for contiguous continuation
   bool walk_valid = false;
   u32 walk_T = 0, walk_B = 0;
@@ -149,6 +153,7 @@ void ecl_hip_close(ecl_hip* h) {
   if (!h) return;
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
   for (int i = 0; i < MUL_NBUF; ++i) {
@@ -158,7 +163,10 @@ void ecl_hip_close(ecl_hip* h) {
     if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-  (void)hipFree(h->d_multmp), (void)hipFree(h->d_ver), (void)hipFree(h->d_rawtext), (void)hipFree(h->d_rawlines);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  (void)hipFree(h->d_multmp[0]), (void)hipFree(h->d_multmp[1]), (void)hipFree(h->d_ver), (void)hipFree(h->d_rawtext), (void)hipFree(h->d_rawlines);
   release_multable(h);
   if (h->ev_s0) (void)hipEventDestroy(h->ev_s0);
   if (h->ev_s1) (void)hipEventDestroy(h->ev_s1);
@@ -336,9 +344,13 @@ static add_kernel_t pick_add_kernel(u32 flags) {
 }
 
 // found records of one call: [0, raw_cap) written by the search kernel; in list mode the confirmed ones are
-// compacted into [raw_cap, raw_cap + cap).  d_counter[0] = records pushed, d_counter[1] = records confirmed.
-#define ECL_LIST_RAW_CAP (1u << 20)
+// compacted into [raw_cap, 2 * raw_cap).  d_counter[0] = records pushed, d_counter[1] = records confirmed.
+// raw_cap = max(cap, 2^20) whatever the caller's `cap` (32 MB of HBM, twice that in list mode): a call that reports
+// ECL_E_OVERFLOW has kept the records that did not fit the caller's buffer, and ecl_hip_fetch_found hands them over
+// without the search kernel running again.
+#define ECL_RAW_CAP_MIN (1u << 20)
 static int ensure_found(ecl_hip* h, u32 cap) {
+  h->last_held = h->last_total = 0;  // every add / mul call comes through here first: the records of the call before are about to be overwritten
   if (cap <= h->found_cap) return ECL_OK;
   if (h->d_found) HIPCHK(h, hipFree(h->d_found));
   h->d_found = nullptr, h->found_cap = 0;
@@ -347,14 +359,23 @@ static int ensure_found(ecl_hip* h, u32 cap) {
   return ECL_OK;
 }
 
-static u32 raw_cap_of(const ecl_hip* h, u32 cap) { return h->d_list ? (cap > ECL_LIST_RAW_CAP ? cap : ECL_LIST_RAW_CAP) : cap; }
+static u32 raw_cap_of(const ecl_hip*, u32 cap) { return cap > ECL_RAW_CAP_MIN ? cap : ECL_RAW_CAP_MIN; }
+static u32 found_words_of(const ecl_hip* h, u32 rcap) { return h->d_list ? 2u * rcap : rcap; }  // records to allocate for a call
+static void found_to_host(ecl_found* out, const ecl_found_dev* tmp, u32 n, bool keep_endo) {
+  for (u32 i = 0; i < n; ++i) {
+    out[i].key_offset = tmp[i].key_offset;
+    memcpy(out[i].h160, tmp[i].h160, 20);
+    out[i].endo = keep_endo ? (uint8_t)(tmp[i].tag & 0xff) : 0, out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
+    out[i].pad[0] = out[i].pad[1] = 0;
+  }
+}
 // after the search kernel has been queued on h->stream: optional list confirm, then counters and records to the host
 static int collect_found(ecl_hip* h, u32 cap, u32 rcap, ecl_found* out, u32* nout, bool keep_endo) {
   const bool lst = h->d_list != nullptr;
   if (lst) {
     const u32 blocks = (rcap + 255) / 256 < 1024 ? (rcap + 255) / 256 : 1024;
     hipLaunchKernelGGL(k_list_filter, dim3(blocks), dim3(256), 0, h->stream, h->d_found, h->d_counter, rcap, h->d_list, h->list_n,
-                       h->d_found + rcap, h->d_counter + 1, cap);
+                       h->d_found + rcap, h->d_counter + 1, rcap);
     HIPCHK(h, hipGetLastError());
   }
   u32 cnts[2] = {0, 0};
@@ -362,23 +383,33 @@ static int collect_found(ecl_hip* h, u32 cap, u32 rcap, ecl_found* out, u32* nou
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const u32 cnt = lst ? cnts[1] : cnts[0];
   const u32 take = cnt < cap ? cnt : cap;
+  h->last_at = lst ? rcap : 0, h->last_held = cnt < rcap ? cnt : rcap, h->last_total = cnt, h->last_endo = keep_endo;
   if (take) {
     std::vector<ecl_found_dev> tmp(take);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found + (lst ? rcap : 0), (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
-    for (u32 i = 0; i < take; ++i) {
-      out[i].key_offset = tmp[i].key_offset;
-      memcpy(out[i].h160, tmp[i].h160, 20);
-      out[i].endo = keep_endo ? (uint8_t)(tmp[i].tag & 0xff) : 0, out[i].compressed = (uint8_t)((tmp[i].tag >> 8) & 1);
-      out[i].pad[0] = out[i].pad[1] = 0;
-    }
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_found + h->last_at, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
+    found_to_host(out, tmp.data(), take, keep_endo);
   }
   *nout = cnt;
   if (lst && cnts[0] > rcap) {  // the bloom let more through than the staging area holds: some were never looked up
     h->err = "list mode: more bloom hits in one call than the device staging area holds";
     *nout = cnts[0];
+    h->last_held = 0, h->last_total = cnts[0];  // nothing to fetch: the confirmed set is incomplete
     return ECL_E_OVERFLOW;
   }
   return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
+}
+
+extern "C" int ecl_hip_fetch_found(ecl_hip* h, uint32_t first, ecl_found* out, uint32_t n, uint32_t* got) {
+  if (!h || !got || (!out && n)) return ECL_E_ARG;
+  *got = 0;
+  if (first >= h->last_held || n == 0) return ECL_OK;
+  const u32 take = h->last_held - first < n ? h->last_held - first : n;
+  HIPCHK(h, hipSetDevice(h->dev));
+  std::vector<ecl_found_dev> tmp(take);
+  HIPCHK(h, hipMemcpy(tmp.data(), h->d_found + h->last_at + first, (size_t)take * sizeof(ecl_found_dev), hipMemcpyDeviceToHost));
+  found_to_host(out, tmp.data(), take, h->last_endo);
+  *got = take;
+  return ECL_OK;
 }
 
 static int default_lanes(ecl_hip* h) {
@@ -417,18 +448,16 @@ static int ensure_table(ecl_hip* h) {
     words_of(&ks[(size_t)i * 8], cur);
     cur = sc_add(cur, s);
   }
-  u32 *d_k = nullptr, *d_w = nullptr;
-  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&d_w, (size_t)B * 16 * sizeof(u32)));
+  dbuf<u32> d_k, d_w;  // freed on every way out (a failed call used to leak them)
+  HIPCHK(h, hipMalloc(&d_k.p, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&d_w.p, (size_t)B * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_tab, (size_t)B * ECL_TAB_STRIDE * sizeof(u32)));
-  HIPCHK(h, hipMemcpyAsync(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_mul_g, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_k, d_w, (u8*)nullptr, B);
+  HIPCHK(h, hipMemcpyAsync(d_k.p, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_mul_g, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_k.p, d_w.p, (u8*)nullptr, B);
   HIPCHK(h, hipGetLastError());
-  hipLaunchKernelGGL(k_tab_to_limbs, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_w, h->d_tab, B);
+  hipLaunchKernelGGL(k_tab_to_limbs, dim3((B + 63) / 64), dim3(64), 0, h->stream, d_w.p, h->d_tab, B);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipFree(d_k));
-  HIPCHK(h, hipFree(d_w));
   h->tab_B = B;
   return ECL_OK;
 }
@@ -443,19 +472,42 @@ extern "C" int ecl_hip_get_geometry(ecl_hip* h, uint32_t* half_group, uint32_t* 
   return ECL_OK;
 }
 
-// Geometry of one call.  The table for half group h->B holds the tables of all smaller ones as prefixes.  A call too
-// short to give every one of the Tmax lanes a whole group takes a smaller half group (down to 128) instead of fewer
-// lanes: the walk only reaches its rate when the chip is oversubscribed with blocks in different phases (2^29 keys:
-// 11.5 Gkeys/s with 1024 x 2^18 lanes, 12.1 with 256 x 2^20; the price is a larger share of the inversion - one per
-// lane and group - which is why the floor was 256 while the inversion was the 270-multiplication chain; with the
-// division steps (fe256.h) 128 x 2^21 lanes is ahead on 2^29-key calls: kernel 12.46 against 12.37 Gkeys/s, whole step
-// 12.26 against 12.21 with its longer lane set-up, profiles/r04_short_calls.txt).  Contiguous calls of one size keep one
-// geometry, so they still continue the resident walk.
-#define ECL_B_FLOOR 128u
+// Geometry of one call.  The table for half group h->B holds the tables of all smaller ones as prefixes, so a call may walk any
+// power-of-two half group up to h->B.  Two costs pull in opposite directions: a lane pays one inversion per group (the division
+// steps cost about five keys' worth of work: + 5 / 2B per key), and a walk with few lanes leaves the chip empty or in lock-step -
+// the kernel only reaches its rate when the slots are oversubscribed with blocks in different phases.  Both were measured
+// (profiles/r05_short_calls.txt: calls of 2^21 ... 2^26 keys at half groups 8 ... 128; profiles/r04_short_calls.txt: 2^29 ... 2^32):
+// the time per key relative to the long-call rate is, to a few per cent, lane_factor(lanes) x (1 + 5 / 2B) with
+//   lanes        2^13  2^14  2^15  2^16  2^17  2^18  2^19  2^20  2^21
+//   lane_factor  10.9   5.5  2.77  1.41  1.17  1.10  1.04  1.00  0.975
+// and the automatic choice is the half group that minimises the product.  That gives 1024 x 2^21 lanes for 2^32 keys, 128 x 2^21 for
+// 2^29 (the per-GPU shard of the named range on 8 GPUs; as round 4 found by sweeping), 32 x 2^18 for 2^24 and 8 x 2^17 for the
+// reference's own MAX_JOB_SIZE of 2^21 keys (main.c:16) - 7.1 Gkeys/s where the round-4 floor of 128 (8192 lanes: 32 workgroups on
+// 256 CUs) gave 1.1.  Contiguous calls of one size keep one geometry, so they still continue the resident walk.
+#define ECL_B_FLOOR 8u  /* k_init_centres_batched parks 144 bytes per lane in the chain scratch (lanes * B * 36 bytes) */
+static double lane_factor(double lanes) {
+  static const double f[] = {10.9, 5.5, 2.77, 1.41, 1.17, 1.10, 1.04, 1.00, 0.975};  // 2^13 ... 2^21 lanes
+  const double l = log2(lanes < 1 ? 1 : lanes);
+  if (l <= 13) return f[0] * exp2(13 - l);  // below: the walk is one chain per lane, time goes with 1 / lanes
+  if (l >= 21) return f[8];
+  const int i = (int)l - 13;
+  return f[i] + (f[i + 1] - f[i]) * (l - (13 + i));
+}
+static u32 auto_half_group(const ecl_hip* h, u64 nkeys) {
+  u32 best = h->B;
+  if (!h->B_auto) return best;
+  double best_cost = 0;
+  for (u32 B = h->B; B >= ECL_B_FLOOR; B >>= 1) {
+    const u64 groups = (nkeys + 2ull * B - 1) / (2ull * B);
+    const double lanes = groups < h->Tmax ? (double)groups : (double)h->Tmax;
+    const double cost = lane_factor(lanes) * (1.0 + 5.0 / (2.0 * B));
+    if (B == h->B || cost < best_cost * 0.995) best = B, best_cost = cost;  // a smaller half group has to win by more than noise
+    if (groups >= h->Tmax) break;  // every lane already has a group of its own: halving further only adds inversions
+  }
+  return best;
+}
 static void call_geometry(const ecl_hip* h, u64 nkeys, u32& B, u32& nb, u32& T) {
-  B = h->B;
-  if (h->B_auto)
-    while (B > ECL_B_FLOOR && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+  B = auto_half_group(h, nkeys);
   const u64 group = 2ull * B, ngroups = (nkeys + group - 1) / group;
   // nb groups per lane, then the smallest lane count (multiple of 256) that covers the range: no lane idles
   // through a mostly masked last group
@@ -467,9 +519,7 @@ static void call_geometry(const ecl_hip* h, u64 nkeys, u32& B, u32& nb, u32& T) 
 // (a caller-set geometry of 2 x 256 lanes reaches that at 2^42 keys; the default one never does below 2^63)
 static bool nkeys_ok(const ecl_hip* h, u64 nkeys) {
   if (nkeys > (1ull << 63)) return false;
-  u32 B = h->B;
-  if (h->B_auto)
-    while (B > ECL_B_FLOOR && nkeys < (u64)h->Tmax * 2 * B) B >>= 1;
+  const u32 B = auto_half_group(h, nkeys);
   const u64 ngroups = (nkeys + 2ull * B - 1) / (2ull * B);
   return (ngroups + h->Tmax - 1) / h->Tmax < (1ull << 32);
 }
@@ -506,7 +556,7 @@ extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
   if ((rc = ensure_gtable(h)) != ECL_OK) return rc;
   if (!nkeys_ok(h, nkeys)) return ECL_E_ARG;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
-  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
   u32 B, nb, T;
   call_geometry(h, nkeys, B, nb, T);
   return ensure_walk_buffers(h, B, T);
@@ -527,7 +577,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   }
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
-  if ((rc = ensure_found(h, rcap + (h->d_list ? cap : 0))) != ECL_OK) return rc;
+  if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
 
   u32 B, nb, T;
   call_geometry(h, nkeys, B, nb, T);

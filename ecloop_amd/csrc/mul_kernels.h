@@ -86,6 +86,8 @@ __device__ __forceinline__ u32 wtab_digit(const u32 kk[9], const wtab& t, u32 w)
 // The point of window w + 1 is requested before the addition of window w's (64 bytes, 16 registers held across one
 // mixed addition): the gathers come from HBM / Infinity Cache and the kernel runs at two waves per SIMD, too few to hide them.
 // Measured on 2^24-scalar calls, 22-bit table, four processes each: 995-1001 M scalars/s with, 980-985 without.
+// (Variants that were built, measured and taken out again - the sum with the scalar in registers and per-lane states, the same work as
+// two kernels, additions one operation at a time, filter tests in place: HISTORY.md and profiles/r04_mul_*.txt.)
 // -y for a negative digit, magnitude 1 (the complete formulas and the first two points of a lazy sum take normalised operands)
 __device__ __forceinline__ fe fe_cneg_weak(const fe& y, u32 neg) {
   const fe m = fe_neg(y, 1);
@@ -111,40 +113,6 @@ __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
 }
 // the complete sum out of line: the fallback of a scalar whose lazy sum ended with Z = 0 (never taken by a random scalar)
 __device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { return wtab_sum(kk, t); }
-// The sum for k_mul_check's hot loop: lazy additions without exceptional cases, Z^2 and Z^3 carried instead of Z (ec.h: xyzz_madd_lazy,
-// 8M + 2S per table point; the caller tests ZZ once at the end), the second point of a sum added to the first as affine + affine (4M + 2S).
-// State: npts = 0 nothing yet, 1 = one table point held as it is (acc.X, acc.Y), >= 2 = XYZZ.  Returns with acc.inf = 1 for an all-zero
-// scalar and ZZ = ZZZ = 1 for a single point.  (The scalar-in-registers form; the kernel ships with wtab_sum_fast below.)
-__device__ __forceinline__ xyzz wtab_sum_xyzz(const u32 kk[9], const wtab t) {
-  xyzz acc;
-  acc.X = fe_zero(), acc.Y = fe_zero(), acc.ZZ = fe_one(), acc.ZZZ = fe_one(), acc.inf = 1;
-  u32 npts = 0, carry = 0, nneg = 0;
-  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  u32 dnext = wtab_recode(t, 0, wtab_digit(kk, t, 0), carry, nneg);
-  if (dnext) {
-    const uint4* e = (const uint4*)(t.p + ((size_t)dnext - 1) * 16);
-    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-  }
-#pragma unroll 1
-  for (u32 w = 0; w < t.nwin; ++w) {
-    const u32 digit = dnext, neg = nneg;
-    const uint4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    dnext = w + 1 < t.nwin ? wtab_recode(t, w + 1, wtab_digit(kk, t, w + 1), carry, nneg) : 0u;
-    if (dnext) {
-      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1) * t.stride + dnext - 1) * 16);
-      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
-    }
-    if (!digit) continue;
-    const u32 xw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, yw[8] = {c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
-    const fe qx = fe_from_words(xw), qy = fe_from_words(yw);
-    // the first two points take their sign on y (normalised: they are subtracted from each other), the later ones on s2 = y ZZZ
-    if (npts == 0) acc.X = qx, acc.Y = fe_cneg_weak(qy, neg), acc.inf = 0;
-    else if (npts == 1) acc = xyzz_mmadd_lazy(acc.X, acc.Y, qx, fe_cneg_weak(qy, neg));
-    else acc = xyzz_madd_lazy(acc, qx, qy, neg);
-    ++npts;
-  }
-  return acc;
-}
 // rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
 // consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
 __global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
@@ -213,16 +181,7 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
-#ifndef ECL_MUL_LOOP_PAIRS
-#define ECL_MUL_LOOP_PAIRS 1  /* the additions inside wtab_sum_fast's loop as interleaved pairs too (+0.5-1 % on 2^24-scalar calls); A/B: 0 */
-#endif
-#ifndef ECL_MUL_FASTSUM
-#define ECL_MUL_FASTSUM 1  /* the low-register window sum (wtab_sum_fast, below) in k_mul_check; A/B: 0 = wtab_sum_xyzz (scalar in registers, per-lane states) */
-#endif
 __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad);
-#ifndef ECL_MUL_RINGS
-#define ECL_MUL_RINGS 1  /* A/B: 0 = every hash finishes its filter test in place */
-#endif
 #define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 #ifndef ECL_MUL_WAVES
 #define ECL_MUL_WAVES 3  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side launches
@@ -233,9 +192,7 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
-#if ECL_MUL_RINGS
   __shared__ u32 q_mem[4][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave (add_kernel.h)
-#endif
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt) return;  // nt is a multiple of 256: whole workgroups leave
   fe prod = fe_one();
@@ -245,26 +202,18 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
   for (u32 r = 0; r < R; ++r) {
     const u32 i = r * nt + t;
     if (i >= n) break;
-#if ECL_MUL_FASTSUM
     u32 bad;
     xyzz acc = wtab_sum_fast(k + (size_t)i * 8, gtab, bad);
     acc.inf = 0;
-    if (__builtin_expect(bad || fe_is_zero(acc.ZZ), 0)) {  // a zero digit (stand-in point) or P = +-Q on the way: the complete sum
+    // a zero digit (stand-in point), or P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) which leaves ZZ = 0 -
+    // and a zero in the product chain would take the thread's other scalars with it: the complete sum, out of line
+    if (__builtin_expect(bad || fe_is_zero(acc.ZZ), 0)) {
       u32 kk[9];
 #pragma unroll
       for (int j = 0; j < 8; ++j) kk[j] = k[(size_t)i * 8 + j];
       kk[8] = 0;
       acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
     }
-#else
-    u32 kk[9];
-    const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
-    kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
-    xyzz acc = wtab_sum_xyzz(kk, gtab);
-    // an addition that met P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) leaves ZZ = 0, and a zero in
-    // the product chain would take the thread's other scalars with it: such a scalar goes through the complete formulas instead
-    if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
-#endif
     infmask |= (acc.inf ? 1u : 0u) << r;
     fe tt, xs, ys, nprod;
     fe_mul_pair(tt, xs, acc.ZZ, acc.ZZZ, acc.X, acc.ZZZ);
@@ -279,10 +228,10 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     prod = nprod;
   }
   fe inv = fe_inv(prod);
-#if ECL_MUL_RINGS
   // the filter test through the add kernel's two candidate rings per wave (add_kernel.h: survivors of probe 0 are parked in LDS and
   // finished 64 at a time): every lane of the wave walks all R rounds - a lane without a scalar (i >= n) or with the point at infinity
   // comes along with live = false and leaves the inversion chain alone - so that the rings' wave-uniform state stays uniform
+  // (+1.7 % at the .blf design density against finishing every hash's test in place, profiles/r04_mul_rings.txt)
   cand_queues q;
   q.a.mem = q_mem[threadIdx.x >> 6][0], q.a.head = 0, q.a.count = 0;
   q.b.mem = q_mem[threadIdx.x >> 6][1], q.b.head = 0, q.b.count = 0;
@@ -304,46 +253,51 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     check_point<A33, A65, false>(a, &q, have && !((infmask >> r) & 1u), x, y, (u64)base + i);
   }
   cand_flush(a, q);
-#else
-#pragma unroll 1
-  for (u32 r = R; r-- > 0;) {
-    const u32 i = r * nt + t;
-    if (i >= n) continue;
-    const u32* p = tmp + (size_t)r * 36 * nt + t;
-    fe X, Y, T, pre;
-#pragma unroll
-    for (int l = 0; l < FE_LIMBS; ++l) {
-      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
-      T.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
-    }
-    const fe ti = fe_mul(inv, pre);
-    inv = fe_mul(inv, T);
-    if ((infmask >> r) & 1u) continue;
-    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
-    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
-  }
-#endif
 }
-// ---- the summing kernel's own form of the window sum (round 4): written for a small register budget (three waves per SIMD) --------
+// ---- k_mul_check's window sum (round 4): written for a small register budget (three waves per SIMD) --------
 // * the scalar stays in memory: a digit is one 8-byte load at the digit's word (L2 / L1 hits after the first window: a wave's scalars
 //   are 2 KiB of contiguous memory) + a shift, not a 16-way select over eight registers, and is fetched one window ahead;
 // * a table point's 16 words are requested after the two multiplications that consume the previous point (u2 = qx ZZ, s2 = qy ZZZ),
 //   so the 18 limbs of one point and the 16 words of the next are never live together;
 // * no per-lane control flow: windows 0 and 1 are added as affine + affine, every later one by the mixed addition; a zero digit
-//   (2^-22 per window for a random scalar; small test scalars have many) takes slot 0 of its row instead and flags the scalar, which the
-//   caller then sends through the complete sum (wtab_sum_complete) like one whose chain degenerated (ZZ = 0).
+//   (2^-26 per window for a random scalar) takes slot 0 of its row instead and flags the scalar, which the caller then sends through
+//   the complete sum (wtab_sum_complete) like one whose chain degenerated (ZZ = 0) - but the high windows in which NO lane of the
+//   wave has a digit (small scalars) are cut off the loop (round 5; before, such input took the complete sum for every scalar).
 __device__ __forceinline__ u32 wtab_digit_mem(const u32* __restrict__ kw, const wtab& t, u32 w) {
   u32 bit = w * t.W, word = bit >> 5, sh = bit & 31u;
   if (word > 6u) word = 6u, sh += 32u;  // the last words: shift further instead of reading past the scalar
-  const u64 v = *(const u64*)(kw + word);  // 4-byte aligned 8-byte load
+  u64 v;
+  __builtin_memcpy(&v, kw + word, 8);  // an 8-byte load from a 4-byte aligned address (odd `word`): one global_load_dwordx2 on gfx950
   return (u32)(v >> sh) & t.per;  // raw digit
 }
+#ifndef ECL_MUL_HOT_GATHERS
+#define ECL_MUL_HOT_GATHERS 0  /* MEASUREMENT BUILD ONLY (wrong points): every gather lands in the first 256 slots of its row, i.e. in cache -
+                                  the same instructions and loads with the table's latency taken away: the upper bound of what ANY deeper
+                                  prefetch of the table points (more registers, LDS staging two windows ahead) could gain; tools/ab_r05b.sh */
+#endif
 __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad) {
+  // Windows that hold a zero digit in EVERY lane of the wave are not walked at all: the loop ends at the highest window in which some
+  // lane has something to add (round 5).  That is what small scalars need - puzzle-range or sequential keys: all of their high windows,
+  // which the reference skips one by one (lib/ecc.c:913) and which used to send every such scalar through the complete sum - and it
+  // costs the loop body nothing: the bound is wave-uniform, found from the scalars' bit lengths (k < 2^(j W - 1) leaves windows >= j
+  // without a digit and without a carry into them).  A zero digit below that bound still takes the stand-in point and flags the scalar.
+  u32 nw = t.nwin;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const uint4 k0 = ((const uint4*)kw)[0], k1 = ((const uint4*)kw)[1];  // (the scalar's own cache line: the digit loads below hit it)
+    const u32 ws[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    u32 bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bits = ws[j] ? 32u * (u32)j + 32u - (u32)__builtin_clz(ws[j]) : bits;
+    while (nw > 2u && __builtin_amdgcn_ballot_w64(bits >= (nw - 1u) * t.W) == 0ull) --nw;
+  }
+#endif
   u32 carry = 0, s0, s1, sn = 0;
   u32 d0 = wtab_recode(t, 0, wtab_digit_mem(kw, t, 0), carry, s0), d1 = wtab_recode(t, 1, wtab_digit_mem(kw, t, 1), carry, s1);
-  u32 dn = t.nwin > 2u ? wtab_recode(t, 2, wtab_digit_mem(kw, t, 2), carry, sn) : 1u;
+  u32 dn = nw > 2u ? wtab_recode(t, 2, wtab_digit_mem(kw, t, 2), carry, sn) : 1u;
   bad = (d0 == 0u) | (d1 == 0u);
   d0 = d0 ? d0 : 1u, d1 = d1 ? d1 : 1u;
+  if (ECL_MUL_HOT_GATHERS) d0 = (d0 & 255u) + 1u, d1 = (d1 & 255u) + 1u;
   xyzz acc;
   {
     const uint4* e0 = (const uint4*)(t.p + ((size_t)d0 - 1) * 16);
@@ -354,28 +308,26 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_cneg_weak(fe_from_words(pyw), s0), fe_from_words(qxw), fe_cneg_weak(fe_from_words(qyw), s1));
   }
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
-  if (t.nwin > 2u) {
+  if (nw > 2u) {
     bad |= dn == 0u;
     dn = dn ? dn : 1u;
+    if (ECL_MUL_HOT_GATHERS) dn = (dn & 255u) + 1u;
     const uint4* e = (const uint4*)(t.p + ((size_t)2 * t.stride + dn - 1) * 16);
     n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
   }
 #pragma unroll 1
-  for (u32 w = 2; w < t.nwin; ++w) {
+  for (u32 w = 2; w < nw; ++w) {
     const u32 xw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w}, yw[8] = {n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
-    const bool more = w + 1u < t.nwin;
+    const bool more = w + 1u < nw;
     const u32 neg = sn;
     dn = more ? wtab_recode(t, w + 1u, wtab_digit_mem(kw, t, w + 1u), carry, sn) : 1u;
-#if ECL_MUL_LOOP_PAIRS
-    fe u2, s2p;
+    fe u2, s2p;  // (the ten operations of an addition as five interleaved pairs: +0.5-1 %, profiles/r04_mul_pairs.txt)
     fe_mul_pair(u2, s2p, fe_from_words(xw), acc.ZZ, fe_from_words(yw), acc.ZZZ);
     const fe s2m = fe_neg(s2p, 1);
-#else
-    const fe u2 = fe_mul(fe_from_words(xw), acc.ZZ), s2p = fe_mul(fe_from_words(yw), acc.ZZZ), s2m = fe_neg(s2p, 1);
-#endif
     if (more) {
       bad |= dn == 0u;
       dn = dn ? dn : 1u;
+      if (ECL_MUL_HOT_GATHERS) dn = (dn & 255u) + 1u;
       const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1u) * t.stride + dn - 1) * 16);
       n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
@@ -386,7 +338,6 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     fe_normalize_weak(h);
     fe rr = fe_add(s2, fe_neg(acc.Y, 3));
     fe_normalize_weak(rr);
-#if ECL_MUL_LOOP_PAIRS
     fe hh, rr2, hhh, v, t1, t2;
     fe_sqr_pair(hh, rr2, h, rr);
     fe_mul_pair(hhh, v, hh, h, acc.X, hh);
@@ -396,106 +347,8 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
     acc.Y = fe_add(t1, fe_neg(t2, 1));
     acc.X = X3;
     fe_mul_pair(acc.ZZ, acc.ZZZ, acc.ZZ, hh, acc.ZZZ, hhh);
-#else
-    const fe hh = fe_sqr(h), hhh = fe_mul(hh, h), v = fe_mul(acc.X, hh);
-    fe X3 = fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_add(v, v), 2));
-    fe_normalize_weak(X3);
-    acc.Y = fe_add(fe_mul(rr, fe_sub(v, X3)), fe_neg(fe_mul(acc.Y, hhh), 1));
-    acc.X = X3;
-    acc.ZZ = fe_mul(acc.ZZ, hh);
-    acc.ZZZ = fe_mul(acc.ZZZ, hhh);
-#endif
   }
   return acc;
-}
-// The same work as two kernels (round 4, ECL_MUL_SPLIT): k_mul_sum = the window sums and the parking, no hashing in its code or in its
-// register budget; k_mul_finish = one inversion per thread, the walk back, hash160 + probe.  Same threads, same chains, same parking
-// space (+ the chain products and infinity masks of a piece: 40 bytes per thread); the pieces of a call alternate on the stream.
-#ifndef ECL_MUL_SUM_WAVES
-#define ECL_MUL_SUM_WAVES 2
-#endif
-#ifndef ECL_MUL_SUM_FAST
-#define ECL_MUL_SUM_FAST 1 /* A/B: 0 = wtab_sum_xyzz (scalar in registers, per-lane states) in the summing kernel */
-#endif
-#ifndef ECL_MUL_FIN_WAVES
-#define ECL_MUL_FIN_WAVES 2
-#endif
-__global__ void __launch_bounds__(256, ECL_MUL_SUM_WAVES) k_mul_sum(const u32* __restrict__ k, u32 n, const wtab gtab, u32* __restrict__ tmp,
-                                                                     u32* __restrict__ chain, u32 nt, u32 R, u32 C) {
-  // nt chains of R scalars each (chain c: scalars c, c + nt, ...), C chains per thread (c = t, t + nt / C, ...): the finishing kernel runs
-  // one thread per chain at twice this kernel's occupancy
-  const u32 t = blockIdx.x * 256u + threadIdx.x, nts = nt / C;
-  if (t >= nts) return;
-#pragma unroll 1
-  for (u32 c = t; c < nt; c += nts) {
-    fe prod = fe_one();
-    u32 infmask = 0;
-#pragma unroll 1
-    for (u32 r = 0; r < R; ++r) {
-      const u32 i = r * nt + c;
-      if (i >= n) break;
-#if ECL_MUL_SUM_FAST
-      u32 bad;
-      xyzz acc = wtab_sum_fast(k + (size_t)i * 8, gtab, bad);
-      acc.inf = 0;
-      // a zero digit on the way (the sum took a stand-in point), or P = +-Q (h = 0 leaves ZZ = 0): the complete sum, out of line
-      if (__builtin_expect(bad || fe_is_zero(acc.ZZ), 0)) {
-        u32 kk[9];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) kk[j] = k[(size_t)i * 8 + j];
-        kk[8] = 0;
-        acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
-      }
-#else
-      u32 kk[9];
-      const uint4 k0 = ((const uint4*)k)[(size_t)i * 2], k1 = ((const uint4*)k)[(size_t)i * 2 + 1];
-      kk[0] = k0.x, kk[1] = k0.y, kk[2] = k0.z, kk[3] = k0.w, kk[4] = k1.x, kk[5] = k1.y, kk[6] = k1.z, kk[7] = k1.w, kk[8] = 0;
-      xyzz acc = wtab_sum_xyzz(kk, gtab);
-      if (!acc.inf && __builtin_expect(fe_is_zero(acc.ZZ), 0)) acc = xyzz_from_jac(wtab_sum_complete(kk, gtab));
-#endif
-      infmask |= (acc.inf ? 1u : 0u) << r;
-      const fe tt = acc.inf ? fe_one() : fe_mul(acc.ZZ, acc.ZZZ);
-      const fe xs = fe_mul(acc.X, acc.ZZZ), ys = fe_mul(acc.Y, acc.ZZ);
-      u32* p = tmp + (size_t)r * 36 * nt + c;
-#pragma unroll
-      for (int l = 0; l < FE_LIMBS; ++l) {
-        p[(size_t)l * nt] = xs.n[l], p[(size_t)(9 + l) * nt] = ys.n[l];
-        p[(size_t)(18 + l) * nt] = tt.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
-      }
-      prod = fe_mul(prod, tt);
-    }
-#pragma unroll
-    for (int l = 0; l < FE_LIMBS; ++l) chain[(size_t)l * nt + c] = prod.n[l];
-    chain[(size_t)9 * nt + c] = infmask;
-  }
-}
-template <bool A33, bool A65>
-__global__ void __launch_bounds__(256, ECL_MUL_FIN_WAVES) k_mul_finish(u32 n, u32 base, add_args a, const u32* __restrict__ tmp,
-                                                                        const u32* __restrict__ chain, u32 nt, u32 R) {
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= nt) return;
-  fe prod;
-#pragma unroll
-  for (int l = 0; l < FE_LIMBS; ++l) prod.n[l] = chain[(size_t)l * nt + t];
-  const u32 infmask = chain[(size_t)9 * nt + t];
-  fe inv = fe_inv(prod);
-#pragma unroll 1
-  for (u32 r = R; r-- > 0;) {
-    const u32 i = r * nt + t;
-    if (i >= n) continue;
-    const u32* p = tmp + (size_t)r * 36 * nt + t;
-    fe X, Y, T, pre;
-#pragma unroll
-    for (int l = 0; l < FE_LIMBS; ++l) {
-      X.n[l] = p[(size_t)l * nt], Y.n[l] = p[(size_t)(9 + l) * nt];
-      T.n[l] = p[(size_t)(18 + l) * nt], pre.n[l] = p[(size_t)(27 + l) * nt];
-    }
-    const fe ti = fe_mul(inv, pre);
-    inv = fe_mul(inv, T);
-    if ((infmask >> r) & 1u) continue;
-    const fe x = fe_mul(X, ti), y = fe_mul(Y, ti);
-    check_point<A33, A65, false>(a, nullptr, true, x, y, (u64)base + i);
-  }
 }
 // `mul -raw` (main.c:505-527): the scalar of a line is the SHA-256 of its bytes.  One lane per line: the line's bytes are
 // gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and

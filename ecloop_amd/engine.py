@@ -294,7 +294,13 @@ class KeySearch:
                 raw, total = self.dev.add_range(s, n, cap=c)
                 if total <= c:
                     break
-                c = total  # overflow: rerun the launch with a buffer that fits (rare: dense filters only)
+                # overflow (dense filters only): the device kept up to max(cap, 2^20) records of the call - read the rest; only
+                # if there were more than that is the launch repeated with a buffer that fits
+                rest = self.dev.fetch_found(c, total - c)
+                if len(rest) == total - c:
+                    raw = np.concatenate([raw, rest])
+                    break
+                c = total
             self._collect(raw, s)
             done += n
 

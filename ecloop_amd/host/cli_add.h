@@ -69,7 +69,13 @@ static void *scan_worker(void *arg) {
     for (;;) {
       rc = ecl_hip_add_range(run->dev[w->g], s.w, n, buf, cap, &cnt);
       if (rc != ECL_E_OVERFLOW) break;
-      cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap); /* dense filter: rerun with a buffer that fits */
+      /* dense filter: the device kept the records that did not fit (up to max(cap, 2^20) per call) - read them; only a call with
+         more hits than that is run again with a buffer that fits */
+      u32 had = cap, got = 0;
+      cap = cnt, buf = realloc(buf, sizeof(ecl_found) * cap);
+      if (!buf) { fprintf(stderr, "out of memory for %u hit records\n", cap); exit(1); }
+      rc = ecl_hip_fetch_found(run->dev[w->g], had, buf + had, cnt - had, &got);
+      if (rc != ECL_OK || got == cnt - had) break;
     }
     if (rc != ECL_OK) die_ecl(run, w->g, rc, "add_range");
     u32 kept = 0;

@@ -47,7 +47,7 @@ typedef struct ecl_hip ecl_hip; /* opaque per-device context */
 #define ECL_E_ARG (-1)      /* bad argument */
 #define ECL_E_HIP (-2)      /* HIP runtime error: ecl_hip_last_error() has the text */
 #define ECL_E_NODEV (-3)    /* no such device / no gfx950 code object for it */
-#define ECL_E_OVERFLOW (-4) /* more hits than `cap`: *nout = total hits, only `cap` records were written */
+#define ECL_E_OVERFLOW (-4) /* more hits than `cap`: *nout = total hits, only `cap` records were written (the rest: ecl_hip_fetch_found) */
 #define ECL_E_NOBLOOM (-5)  /* add/mul called before ecl_hip_set_bloom */
 #define ECL_E_RANGE (-6)    /* range touches the scalar 0 (mod n) neighbourhood the method cannot represent */
 #define ECL_E_SELFTEST (-7) /* the device code failed its known-answer / cross-path self-test (miscompile, bad GPU) */
@@ -113,7 +113,8 @@ int ecl_hip_sort_list(ecl_hip *h, uint32_t (*h160)[5], uint64_t n, uint64_t *kep
    mul_batch report a hash only if it passed the bloom probe AND is in the list (a small kernel after the search
    kernel looks the bloom hits up by binary search; the list takes 20 bytes per entry of HBM); n = 0 removes the
    list again (bloom-only reporting).  ECL_E_ARG if the entries are not strictly increasing.  In list mode one call
-   can stage max(cap, 2^20) bloom hits; beyond that it returns ECL_E_OVERFLOW with *nout = the number of bloom hits. */
+   can stage max(cap, 2^20) bloom hits; beyond that it returns ECL_E_OVERFLOW with *nout = the number of bloom hits
+   (and nothing to fetch: repeat the call with cap = *nout). */
 int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 
 /* Hash the nkeys keys  start, start+s, ..., start+(nkeys-1)*s  (s = 2^ord_offs; every encoding / endo variant
@@ -124,6 +125,15 @@ int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
    (more than 2^63, or more than 2^32 groups per lane - only reachable with a tiny caller-set geometry). */
 int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
+
+/* The records of the LAST ecl_hip_add_range / ecl_hip_mul_batch(_raw) call of this context that did not fit its `out`: a call
+   keeps up to max(cap, 2^20) records on the device (32 MB), so after ECL_E_OVERFLOW (*nout = total > cap) the caller reads
+   records [first, first + n) - the call itself delivered [0, cap) - instead of repeating a launch that may have walked
+   2^32 keys.  *got = records written to `out` (fewer than n only if the call produced more than the device kept, i.e. more
+   than max(cap, 2^20): then - and only then - the call has to be repeated with cap = total, as before).  Valid until the
+   next add / mul call on the context.  The reference has no counterpart: its sink writes every hit as it is found
+   (ctx_write_found, main.c:182-203), there is no buffer to overflow. */
+int ecl_hip_fetch_found(ecl_hip *h, uint32_t first, ecl_found *out, uint32_t n, uint32_t *got);
 
 /* Optional: allocate now what a later ecl_hip_add_range of `nkeys` keys with record capacity `cap` will need (table,
    lane centres, prefix-product chains, record buffer), so that the first call does not pay for it.  The reference has

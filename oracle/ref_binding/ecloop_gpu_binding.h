@@ -22,17 +22,23 @@ static void gpu_die(ctx_t *ctx, int g, const char *what, int rc) {
 }
 
 /* once per run, after ord_offs has its final value (cmd_rnd lowers it, main.c:620) and before the workers start:
-   one context per GPU, -t = number of GPUs (one host thread per device, main.c:445-447 creates them as before) */
+   one context per GPU, -t = number of contexts (one host thread per context, main.c:445-447 creates them as before) */
 static void gpu_init(ctx_t *ctx) {
   if (ctx->gpu_count) return;
-  int n = ecl_hip_device_count();
-  if (n <= 0) { fprintf(stderr, "no GPU visible\n"); exit(1); }
+  const int real = ecl_hip_device_count();
+  if (real <= 0) { fprintf(stderr, "no GPU visible\n"); exit(1); }
+  /* contexts = GPUs, unless ECLOOP_GPU_CONTEXTS=N asks for N of them (context g on device g mod GPUs): several worker threads
+     per GPU overlap one job's host side (hit records, calc_priv, pk_verify_hash, the sink) with the next job's kernel - and it
+     is how a one-GPU box runs the -t N code path (gpu_claim, per-thread hit buffers) */
+  int n = real;
+  const char *want = getenv("ECLOOP_GPU_CONTEXTS");
+  if (want && atoi(want) > 0) n = atoi(want);
   if (n > GPU_MAX) n = GPU_MAX;
   if ((size_t)n > ctx->threads_count) n = (int)ctx->threads_count;
-  ctx->threads_count = (size_t)n; /* more host threads than devices would only queue behind each other */
+  ctx->threads_count = (size_t)n; /* more host threads than contexts would only queue behind each other */
   const uint32_t flags = (ctx->check_addr33 ? ECL_ADDR33 : 0) | (ctx->check_addr65 ? ECL_ADDR65 : 0) | (ctx->use_endo ? ECL_ENDO : 0);
   for (int g = 0; g < n; ++g) {
-    int rc = ecl_hip_open(&ctx->gpu[g], g, flags, ctx->cmd == CMD_MUL ? 0 : ctx->ord_offs);
+    int rc = ecl_hip_open(&ctx->gpu[g], g % real, flags, ctx->cmd == CMD_MUL ? 0 : ctx->ord_offs);
     if (rc != ECL_OK) gpu_die(ctx, g, "ecl_hip_open", rc);
     rc = ecl_hip_set_bloom(ctx->gpu[g], (const uint64_t *)ctx->blf.bits, ctx->blf.size); /* the very words blf_has reads (utils.c:277-288) */
     if (rc != ECL_OK) gpu_die(ctx, g, "ecl_hip_set_bloom", rc);
@@ -45,10 +51,9 @@ static int gpu_claim(ctx_t *ctx) { return (int)(__atomic_fetch_add(&ctx->gpu_nex
 
 /* hit records of one call; grown to the count the library reports when a call overflows (ECL_E_OVERFLOW) */
 typedef struct gpu_hits_t { ecl_found *rec; uint32_t cap; } gpu_hits_t;
-static void gpu_hits_reserve(gpu_hits_t *h, uint32_t cap) {
+static void gpu_hits_reserve(gpu_hits_t *h, uint32_t cap) { /* keeps what the buffer holds */
   if (cap <= h->cap) return;
-  free(h->rec);
-  h->rec = malloc((size_t)cap * sizeof(ecl_found)), h->cap = cap;
+  h->rec = realloc(h->rec, (size_t)cap * sizeof(ecl_found)), h->cap = cap;
   if (!h->rec) { fprintf(stderr, "out of memory for %u hit records\n", cap); exit(1); }
 }
 
@@ -66,9 +71,13 @@ static void gpu_batch_add(ctx_t *ctx, int g, const fe pk, size_t iterations) {
   gpu_hits_reserve(&hits, 1u << 16);
   uint32_t n = 0;
   int rc = ecl_hip_add_range(ctx->gpu[g], (const uint64_t *)pk, nkeys, hits.rec, hits.cap, &n);
-  if (rc == ECL_E_OVERFLOW) { /* e.g. an all-ones filter: every hash is a hit */
+  if (rc == ECL_E_OVERFLOW) { /* e.g. an all-ones filter: every hash is a hit.  The device kept the records that did not fit
+                                 (up to max(cap, 2^20) per call): read them; only beyond that is the job run again */
+    const uint32_t had = hits.cap;
+    uint32_t got = 0;
     gpu_hits_reserve(&hits, n);
-    rc = ecl_hip_add_range(ctx->gpu[g], (const uint64_t *)pk, nkeys, hits.rec, hits.cap, &n);
+    rc = ecl_hip_fetch_found(ctx->gpu[g], had, hits.rec + had, n - had, &got);
+    if (rc == ECL_OK && got != n - had) rc = ecl_hip_add_range(ctx->gpu[g], (const uint64_t *)pk, nkeys, hits.rec, hits.cap, &n);
   }
   if (rc != ECL_OK) gpu_die(ctx, g, "ecl_hip_add_range", rc);
   for (uint32_t i = 0; i < n; ++i) {

@@ -66,10 +66,18 @@ class FakeDevice:
             off = ((k - start) % orc.N) >> self.offs
             if off < nkeys and (self.list is None or tuple(int(w) for w in r.h160) in self.list):
                 recs.append((off, [int(w) for w in r.h160], r.endo, r.compressed))
-        arr = np.zeros(min(len(recs), cap), dtype=capi.FOUND_DTYPE)
-        for j, (off, h, e, c) in enumerate(recs[:cap]):
+        arr = np.zeros(len(recs), dtype=capi.FOUND_DTYPE)
+        for j, (off, h, e, c) in enumerate(recs):
             arr[j]["key_offset"], arr[j]["h160"], arr[j]["endo"], arr[j]["compressed"] = off, h, e, c
-        return arr, len(recs)
+        self.kept = arr[: max(cap, self.keep_min)]  # what the device keeps of a call (the library: max(cap, 2^20) records)
+        return arr[:cap].copy(), len(recs)
+
+    keep_min = 1 << 20
+    fetches = []
+
+    def fetch_found(self, first, n):
+        FakeDevice.fetches.append((first, n))
+        return self.kept[first : first + n].copy()
 
     def diag_mulg(self, ks):
         pts = [orc.point_of(k) for k in ks]

@@ -1,7 +1,8 @@
-"""The A/B switches kept in the device source (-DECL_* : the alternatives DESIGN.md's measurements were taken against - the two-kernel
-form of `mul`, the scalar-in-registers window sum, operations one by one instead of in pairs, filter tests in place, the addition-chain
-inversion, unpacked matrix rows of the division steps) must keep compiling: a syntax-only pass of hipcc over the library's translation
-unit with all of them flipped (seconds, no code generation).  Skipped without hipcc."""
+"""The A/B switches still kept in the device source (-DECL_* : alternatives DESIGN.md's measurements were taken against - field operations
+one by one instead of in pairs, the addition-chain inversion, unpacked matrix rows of the division steps, two staging buffers) must keep
+compiling: a syntax-only pass of hipcc over the library's translation unit with all of them flipped (seconds, no code generation).
+Skipped without hipcc.  (Round 5 removed the variants that had been measured and rejected: the two-kernel form of `mul`, the window sum
+with the scalar in registers, filter tests in place, the deferred / quarter-wave probes of the add kernel - HISTORY.md.)"""
 import os
 import shutil
 import subprocess
@@ -9,11 +10,10 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLIPPED = ["-DECL_MUL_SPLIT=1", "-DECL_MUL_SUM_FAST=0", "-DECL_MUL_FASTSUM=0", "-DECL_MUL_PAIRS=0", "-DECL_MUL_LOOP_PAIRS=0", "-DECL_MUL_RINGS=0",
-           "-DECL_FE_INV_DIVSTEPS=0", "-DECL_DS_PACKED=0", "-DMUL_NBUF=2"]
+FLIPPED = ["-DECL_MUL_PAIRS=0", "-DECL_FE_INV_DIVSTEPS=0", "-DECL_DS_PACKED=0", "-DMUL_NBUF=2"]
 
 
-@pytest.mark.parametrize("flags", [FLIPPED, ["-DECL_MUL_SPLIT=1", "-DECL_MUL_SUM_WAVES=3", "-DECL_MUL_FIN_WAVES=3"]], ids=["all-flipped", "two-kernel-3-waves"])
+@pytest.mark.parametrize("flags", [FLIPPED, ["-DECL_MUL_WAVES=2"]], ids=["all-flipped", "mul-2-waves"])
 def test_alternative_builds_still_compile(flags):
     hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
     if not hipcc:

@@ -20,6 +20,7 @@ from fake_device import FakeDevice  # noqa: E402
 @pytest.fixture
 def fake(monkeypatch):
     FakeDevice.calls = []
+    FakeDevice.fetches = []
     monkeypatch.setattr(engine, "Device", FakeDevice)
     return FakeDevice
 
@@ -51,6 +52,19 @@ def test_overflow_retry_and_endo_private_keys(fake):
     g = G["dense_fp_cu_endo"]
     from synth import synth_bloom_words
     words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    ks = engine.KeySearch(engine.Filter(words), a33=True, a65=True, endo=True)
+    ks.add_keys(0x8000, 2048, cap=8)
+    assert orc.digest([r.line() for r in ks.found]) == g["sha256_sorted"]
+    # the records beyond the caller's buffer are read from what the device kept: one launch, one fetch
+    assert len(fake.calls) == 1 and fake.fetches == [(8, g["count"] - 8)]
+
+
+def test_overflow_beyond_what_the_device_keeps_reruns_the_launch(fake, monkeypatch):
+    """more hits than the device keeps of one call (the library: max(cap, 2^20)): the fetch comes back short and the launch is repeated"""
+    g = G["dense_fp_cu_endo"]
+    from synth import synth_bloom_words
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    monkeypatch.setattr(FakeDevice, "keep_min", 16)
     ks = engine.KeySearch(engine.Filter(words), a33=True, a65=True, endo=True)
     ks.add_keys(0x8000, 2048, cap=8)
     assert orc.digest([r.line() for r in ks.found]) == g["sha256_sorted"]

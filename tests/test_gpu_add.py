@@ -137,8 +137,40 @@ def test_overflow_is_reported():
     try:
         d.set_geometry(64, 256)
         d.set_bloom(ONES)
+        d.reset_timing()
         recs, n = d.add_range(0x8000, 4096, cap=100)
         assert n == 4096 and len(recs) == 100
+        # the other 3996 records are still on the device (it keeps max(cap, 2^20) per call): fetched, not recomputed
+        rest = d.fetch_found(100, n - 100)
+        assert len(rest) == 3996 and d.timing()[1] == 1  # one search-kernel launch so far
+        tail = d.fetch_found(4000, 1000)  # a request past the end is cut, one past it is empty
+        assert len(tail) == 96 and len(d.fetch_found(4096, 5)) == 0
+        whole, n2 = d.add_range(0x8000, 4096, cap=4096)
+        assert n2 == 4096
+        key = lambda a: sorted((int(r["key_offset"]), int(r["compressed"]), tuple(int(w) for w in r["h160"])) for r in a)
+        assert key(np.concatenate([recs, rest])) == key(whole) and key(tail) == key(rest[-96:])
+        assert len(d.fetch_found(0, 10)) == 10  # the latest call's records (it fitted: nothing was lost, they are still readable)
+    finally:
+        d.close()
+
+
+def test_overflow_in_list_mode_fetches_the_confirmed_records():
+    """device-side list confirm + a caller buffer that is too small: the confirmed records beyond it are fetched too"""
+    from ecloop_amd import Device
+    d = Device(0)
+    try:
+        d.set_geometry(64, 256)
+        d.set_bloom(ONES)
+        whole, n = d.add_range(0x8000, 4096, cap=4096)
+        hs = np.array(sorted({tuple(int(w) for w in r["h160"]) for r in whole[::3]}), dtype=np.uint32)
+        d.set_list(hs)
+        d.reset_timing()
+        recs, n = d.add_range(0x8000, 4096, cap=50)
+        assert n == len(hs) and len(recs) == 50
+        rest = d.fetch_found(50, n - 50)
+        assert len(rest) == n - 50 and d.timing()[1] == 1
+        got = sorted(tuple(int(w) for w in r["h160"]) for r in np.concatenate([recs, rest]))
+        assert got == [tuple(int(w) for w in h) for h in hs]
     finally:
         d.close()
 
@@ -359,6 +391,45 @@ def test_mul_every_window_width_against_double_and_add(W):
             d.set_mul_window(27)
         with pytest.raises(Exception):
             d.set_mul_window(7)
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("W", [9, 16, 22, 26])
+def test_mul_short_scalars_cut_the_window_loop(W):
+    """wtab_sum_fast ends its loop at the highest window in which some lane of the WAVE has a digit (round 5: small scalars no longer take
+    the complete sum one by one).  The bound comes from the scalars' bit lengths, and the signed recoding can carry one window further
+    than the bits reach, so: whole waves of scalars of every bit length 1..256 (thread t of a short batch owns scalar t, a wave = 64
+    consecutive ones), the values around every 2^(jW-1) (where the carry into window j starts) and 2^(jW), waves that mix one long
+    scalar among short ones, consecutive keys from a puzzle range, and 0.  Every scalar against the double-and-add kernel."""
+    from ecloop_amd import Device
+    rng = np.random.default_rng(1000 + W)
+    ks = []
+    for bits in range(1, 257):  # one wave per bit length: every lane below 2^bits, lane 0 exactly bits long
+        wave = [int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62) | (int(rng.integers(0, 1 << 62)) << 124) | (int(rng.integers(0, 1 << 62)) << 186) |
+                (int(rng.integers(0, 1 << 8)) << 248) for _ in range(64)]
+        wave = [(v & ((1 << bits) - 1)) or 1 for v in wave]
+        wave[0] |= 1 << (bits - 1)
+        ks += wave
+    nwin = (256 + W - 1) // W
+    for j in range(1, nwin):  # the carry boundary of every window, a whole wave each (so that the bound is the lanes' own)
+        for base in ((1 << (j * W - 1)), (1 << (j * W))):
+            ks += [max(1, base + d) for d in range(-32, 32)]
+    for j in range(2, nwin):  # one long scalar in a wave of short ones, in lane 0, 17 and 63
+        for lane in (0, 17, 63):
+            wave = [int(rng.integers(1, 1 << 40)) for _ in range(64)]
+            wave[lane] = (1 << (j * W + 3)) | int(rng.integers(0, 1 << 60))
+            ks += wave
+    ks += [(1 << 65) + i for i in range(256)] + [0] * 64 + [1] * 64
+    K = np.array([[(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for v in ks], dtype=np.uint64)
+    d = Device(0)
+    try:
+        d.set_bloom(ONES)
+        d.set_mul_window(W)
+        assert _mul_all_against_double_and_add(d, K) == len(ks) - 64  # the 64 zeros have no point
+        # ... and as a long batch, where a thread owns several scalars (scalar i = r * threads + t)
+        big = np.concatenate([K] * ((1 << 18) // len(K) + 1))
+        assert _mul_all_against_double_and_add(d, big) == len(big) - 64 * ((1 << 18) // len(K) + 1)
     finally:
         d.close()
 

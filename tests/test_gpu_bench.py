@@ -108,6 +108,46 @@ def test_bench_two_ranks_strong_and_weak_legs(control):
     check_two(last_json(pr.stdout), "torch.distributed.run")
 
 
+@pytest.mark.parametrize("launcher", ["threads", "ranks"])
+def test_bench_gpus_8_shared(launcher):
+    """the shape the driver's SCALE run ends on - `--gpus 8` - on whatever GPUs this box has (one: ECL_BENCH_SHARE_GPU=1 folds worker g
+    onto device g mod count), in both launcher shapes: eight device threads in one process, and eight ranks under torch.distributed.run
+    with the rendezvous over gloo.  Eight contexts, eight filters and eight sets of walk buffers live on the device(s) at once (the lane
+    count is cut back to what the free HBM allows, ecloop_hip.hip: default_lanes); every shard finds the planted keys of ITS part of the
+    range (bench.py aborts otherwise), and the line is timed over the slowest worker."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ngpu < 8:
+        env["ECL_BENCH_SHARE_GPU"] = "1"
+    tail = ["--gpus", "8", "--keys-log2", "29", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-secondary"]
+    if launcher == "threads":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--control", "gloo"] + tail
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=ROOT, env=env)
+    assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
+    r = last_json(pr.stdout)
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["config"]["keys_per_gpu_per_step"] == 1 << 26
+    assert ("torch.distributed.run" if launcher == "ranks" else "in-process device threads") in r["config"]["launcher"]
+    sh = sorted(r["config"]["shards"], key=lambda x: x["worker"])
+    assert [x["worker"] for x in sh] == list(range(8)) and [x["gpu"] for x in sh] == [g % max(ngpu, 1) if ngpu < 8 else g for g in range(8)]
+    # contiguous shards that tile the one 2^29-key range
+    assert sum(x["keys_per_step"] for x in sh) == 1 << 29
+    assert [int(x["first_key"], 16) for x in sh] == [0x100000000 + g * (1 << 26) for g in range(8)]
+    # the 16 planted keys (bench.py: build_filter) are spread over the range; each was found by the shard whose keys contain it
+    assert sum(x["planted_checked"] for x in sh) == 16 and r["config"]["planted_checked"] == 16
+    assert all(x["found_per_step"] >= x["planted_checked"] for x in sh) and sum(x["planted_checked"] > 0 for x in sh) >= 4
+    # MAX over the workers: the step is as long as the slowest shard, and the value is the whole job over that time
+    assert r["ms_per_step"] >= max(x["ms_per_step"] for x in sh) * 0.999
+    assert abs(r["value"] - (1 << 29) / (r["ms_per_step"] * 1e3)) / r["value"] < 1e-3
+    assert all(x["lanes"] >= 256 * 256 for x in sh)  # every context got a walk that fills the chip, none failed for memory
+    w = r["weak_scaling"]  # the other leg: 2^29 keys per worker
+    assert w["keys_per_gpu_per_step"] == 1 << 29 and abs(w["value"] - 8 * (1 << 29) / (w["ms_per_step"] * 1e3)) / w["value"] < 1e-3
+    assert "cpu_baseline" not in r and "secondary" not in r
+
+
 def test_bench_ranks_are_matched_to_physical_gpus():
     """under torch.distributed.run a rank takes device LOCAL_RANK, or - when the launcher shows every rank only its own GPU
     (HIP_VISIBLE_DEVICES per rank) - device 0 of what it sees; ranks that end up on the SAME physical GPU (told by PCI address over

@@ -30,11 +30,11 @@ def ecloop_gpu():
     return BIN
 
 
-def run(binary, args, tmp_path, name, stdin_path=None, quiet=True):
+def run(binary, args, tmp_path, name, stdin_path=None, quiet=True, env=None):
     out = str(tmp_path / (name + ".txt"))
     cmd = [binary] + args + (["-q", "-o", out] if quiet else ["-o", out])
     pr = subprocess.run(cmd, stdin=open(stdin_path, "rb") if stdin_path else subprocess.DEVNULL, stdout=subprocess.PIPE,
-                        stderr=subprocess.PIPE, timeout=900)
+                        stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, **env) if env else None)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-2000:]
     status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
     lines = sorted(l.rstrip("\n") for l in open(out)) if os.path.exists(out) else []
@@ -124,3 +124,61 @@ def test_rnd_single_window_runs(ecloop_gpu, tmp_path):
         m = re.search(r"^([\d,]+) / ([\d,]+) ~ [\d.]+s$", text, re.M)
         assert m and (int(m.group(1).replace(",", "")), int(m.group(2).replace(",", ""))) == (g["window_found"], g["window_checked"])
         assert len(lines) == g["count"] and digest(lines) == g["sha256_sorted"] and lines[:16] == g["head"], name
+
+
+def with_threads(args, t):
+    args = list(args)
+    if "-t" in args:
+        args[args.index("-t") + 1] = str(t)
+    else:
+        args += ["-t", str(t)]
+    return args
+
+
+def test_four_worker_threads_on_four_contexts(ecloop_gpu, tmp_path):
+    """`-t 4`: the reference's scheduler hands its 2^21-key jobs to four worker threads (main.c:405-435, 445-447), each bound to its own
+    context by gpu_claim, each with its own hit buffer.  ECLOOP_GPU_CONTEXTS=4 opens four contexts whatever the number of GPUs (context
+    g on device g mod GPUs), so the path runs on a one-GPU box too.  Same found sets and status counters as the single-thread goldens:
+    list mode over 8 jobs, the sparse filter's false positives over two jobs, the 24 576-line -a cu -endo dump, `make mul`, an rnd
+    window; then a 32-job scan against its own -t 1 run."""
+    env = {"ECLOOP_GPU_CONTEXTS": "4"}
+    puz = os.path.join(GOLD, "btc-puzzles-hash")
+    g = G["make_add_8000_ffffff"]
+    lines, status, banner = run(ecloop_gpu, ["add", "-f", puz, "-r", "8000:ffffff", "-t", "4"], tmp_path, "t4_list", env=env)
+    assert lines == sorted(g["lines"]) and counts(status) == (g["status_found"], g["status_checked"])
+    assert "threads: 4 ~" in banner, banner  # main.c:849 prints the -t it was given; gpu_init keeps it (4 contexts)
+    ones = blf_for({}, tmp_path, "ones")
+    for name in ("sparse_fp33_two_jobs", "dump_cu_endo_8000_87ff", "dense_fp_cu_endo"):
+        g = G[name]
+        args = with_threads(g["args"], 4)
+        args[args.index("-f") + 1] = blf_for(g, tmp_path, name) if g.get("bloom") else ones
+        lines, status, _ = run(ecloop_gpu, args, tmp_path, "t4_" + name, env=env)
+        assert len(lines) == g["count"] and digest(lines) == g["sha256_sorted"], name
+        assert counts(status) == (g["status_found"], g["status_checked"]), name
+    g = G["make_mul_bw"]
+    lines, status, _ = run(ecloop_gpu, ["mul", "-f", os.path.join(GOLD, "btc-bw-hash"), "-t", "4", "-a", "cu"], tmp_path, "t4_mul",
+                           stdin_path=os.path.join(GOLD, "btc-bw-priv"), env=env)
+    assert len(lines) == 1080 and digest(lines) == g["sha256_sorted"] and counts(status) == (1080, 1080)
+    g = G["rnd_d0_22_cu_endo"]
+    args = with_threads(g["args"], 4)
+    args[args.index("-f") + 1] = blf_for(g, tmp_path, "t4_rnd")
+    lines, _, text = run(ecloop_gpu, args, tmp_path, "t4_rnd", env=env)
+    assert len(lines) == g["count"] and digest(lines) == g["sha256_sorted"]
+    # a long scan: 2^26 keys = 32 jobs over the four contexts, bloom-only with the sparse filter; the found set equals the -t 1 run's
+    g = G["sparse_fp33_two_jobs"]
+    blf = blf_for(g, tmp_path, "t4_long")
+    one, s1, _ = run(ecloop_gpu, ["add", "-f", blf, "-r", "100000000:103ffffff", "-t", "1"], tmp_path, "t1_long")
+    four, s4, _ = run(ecloop_gpu, ["add", "-f", blf, "-r", "100000000:103ffffff", "-t", "4"], tmp_path, "t4_long", env=env)
+    assert one == four and len(one) > 0 and counts(s1) == counts(s4) == (len(one), 1 << 26)
+
+
+def test_a_job_with_more_hits_than_the_hit_buffer(ecloop_gpu, tmp_path):
+    """all-ones filter, one 2^17-key job: 131 072 hits against the binding's 2^16-record buffer - the call reports ECL_E_OVERFLOW and the
+    other half is fetched from the device (ecl_hip_fetch_found), the kernel is not run again; every line equals the oracle's"""
+    import orc
+    ones = blf_for({}, tmp_path, "ones")
+    lines, status, _ = run(ecloop_gpu, ["add", "-f", ones, "-r", "8000:27fff", "-t", "1"], tmp_path, "overflow")
+    rc, out, n, checked, hashed = orc.add_range(orc.OrcFilter(bloom_words=np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64)), 0x8000, 0x27fff,
+                                                verify=False, threads=4, cap=1 << 18)
+    assert rc == 0 and n == hashed == 1 << 17
+    assert lines == sorted(orc.found_lines(out, n)) and counts(status) == (1 << 17, checked)

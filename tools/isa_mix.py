@@ -162,6 +162,38 @@ def analyse(path=ASM, kernel=K_ADD33):
     return res
 
 
+K_MUL_CU = "_Z11k_mul_checkILb1ELb1EEvPKjjj4wtab8add_argsPjjj"
+
+
+def analyse_mul(path=ASM, kernel=K_MUL_CU, nwin=10):
+    """k_mul_check (mul_kernels.h): loop nest = {sum loop (one trip per scalar) > window loop (nwin - 2 trips per scalar: windows 0 and 1
+    are added before it), walk-back loop (one trip per scalar: two field multiplications pairs + the hash160s + stage-1 probes; its
+    children are the rarely taken ring-drain loops), three ring-flush loops after it}.  Per-scalar static estimate of the class mix =
+    sum loop + (nwin - 2) x window loop + walk-back loop, each exclusive of its children (the inversion - one per thread, shared by the
+    thread's scalars - and the out-of-line complete sum are left out: the PMC count is the truth for the total, the SHARES come from here)."""
+    bl, _ = blocks(path, kernel)
+    parent, depth = loop_tree(path, kernel)
+    excl = {h: zero() for h in parent}
+    total = zero()
+    for b in bl:
+        for k in KEYS:
+            total[k] += b["c"][k]
+            if b["header"] in excl:
+                excl[b["header"]][k] += b["c"][k]
+    kids = {h: [c for c in parent if parent[c] == h] for h in parent}
+    top = [h for h in parent if depth[h] == 1]
+    # the window loop: the depth-2 loop with the most multiply-adds; the sum loop is its parent; the walk-back loop: the hash-heavy one
+    win = max((h for h in parent if depth[h] == 2), key=lambda h: excl[h]["mad64"])
+    summ = parent[win]
+    back = max((h for h in top if h != summ), key=lambda h: excl[h]["other"])
+    est = {k: float(excl[summ][k]) + (nwin - 2) * excl[win][k] + excl[back][k] for k in ("valu", "mad64", "fast", "other")}
+    return {"kernel": kernel, "total": total, "sum_loop": excl[summ], "window_loop": excl[win], "walk_back_loop": excl[back], "windows": nwin,
+            "per_scalar_static": est,
+            "fingerprint": {"kernel_valu": total["valu"], "window_loop_valu": excl[win]["valu"], "window_loop_mad64": excl[win]["mad64"],
+                            "walk_back_loop_valu": excl[back]["valu"], "scratch_instr": total["scratch"],
+                            "window_loop_scratch": excl[win]["scratch"]}}
+
+
 def spills(path=ASM, prefix="_Z5k_add"):
     """vgpr_spill_count / private_segment_fixed_size / vgpr_count of every instantiation of the add kernel, from the code
     object's metadata (DESIGN.md states these numbers; tests/test_profiles_fresh.py compares)"""
@@ -182,6 +214,11 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     path = args[0] if args else ASM
     kernel = args[1] if len(args) > 1 else K_ADD33
+    if "k_mul_check" in kernel:
+        a = analyse_mul(path, kernel)
+        print(json.dumps(a, indent=1) if "--json" in sys.argv else "%s\nper scalar (static, %d windows): %s\nfingerprint: %s" % (
+            kernel, a["windows"], {k: round(v, 1) for k, v in a["per_scalar_static"].items()}, a["fingerprint"]))
+        return
     a = analyse(path, kernel)
     if "--json" in sys.argv:
         print(json.dumps(a, indent=1))
