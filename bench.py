@@ -622,7 +622,45 @@ def _roofline_from(kind, ops_key, rate_per_s, what):
     t = prof.get("traffic") or {}
     if t.get("bytes_per_unit_reported") is not None:
         r["traffic_bytes_per_unit_reported"] = round(t["bytes_per_unit_reported"], 1)
+    if kind == "mul":
+        r["mix_ceiling"] = mul_mix_ceiling(ops, rate_per_s, prof)
     return r
+
+
+def mul_mix_ceiling(ops, rate_per_s, prof):
+    """what k_mul_check's own instruction stream allows: class shares of the library being timed (tools/isa_mix.py: analyse_mul - sum loop +
+    8 trips of the window loop + walk-back loop, static) x the per-class issue rates of the microbenchmark (the headline profile's table)
+    -> mean SIMD-clocks per instruction -> scalars/s at the nominal 2.4 GHz and at the clock this kernel really sustains (the multiply-add
+    heavy stream is power-limited: 2.1-2.2 GHz by GRBM_GUI_ACTIVE against 2.33 for the add kernel)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_mix
+        m = isa_mix.analyse_mul()
+        st = m["per_scalar_static"]
+        head, _ = load_profile()
+        ub = ((head or {}).get("ubench_cycles_per_wave_instr") or {}).get("waves_per_simd_8") or {}
+        c_fast = min([ub[k] for k in ("v_add_u32_e32   (distinct regs)", "v_bitop3_b32    (distinct regs)", "v_add_u32 (e32)") if k in ub] or [0])
+        c_slow, c_mad = ub.get("v_alignbit_b32"), ub.get("v_mad_u64_u32")
+        if not (c_fast and c_slow and c_mad):
+            return None
+        sh = {k: st[k] / st["valu"] for k in ("mad64", "fast", "other")}
+        cyc = sh["mad64"] * c_mad + sh["fast"] * c_fast + sh["other"] * c_slow
+        ceil_nominal = PEAK_4CYCLE * 1e12 * 4.0 / (ops * cyc)
+        out = {"class_shares": {k: round(v, 3) for k, v in sh.items()}, "cycles_per_class": {"mad64": c_mad, "double_rate": c_fast, "other": c_slow},
+               "mean_cycles_per_instr": round(cyc, 3), "ceiling_mscalars_s": round(ceil_nominal / 1e6, 1), "frac": round(rate_per_s / ceil_nominal, 4),
+               "fingerprint": m["fingerprint"], "fingerprint_matches_profile": (prof.get("static_mix") or {}).get("fingerprint") == m["fingerprint"],
+               "note": "per-class rates of the microbenchmark at the nominal 2.4 GHz; shares: static, trip-weighted (tools/isa_mix.py), scaled to the PMC count"}
+        # the double-rate opcodes only reach 2.5 clocks in long runs; between multiply-adds they issue like any other instruction
+        out["mean_cycles_per_instr_double_rate_priced_singly"] = round(sh["mad64"] * c_mad + (1.0 - sh["mad64"]) * c_slow, 3)
+        ghz = (prof.get("derived") or {}).get("clock_ghz")
+        if ghz:
+            out["at_sustained_clock"] = {"clock_ghz": round(ghz, 3), "ceiling_mscalars_s": round(ceil_nominal * ghz / 2.4 / 1e6, 1),
+                                         "frac": round(rate_per_s / (ceil_nominal * ghz / 2.4), 4),
+                                         "measured_simd_cycles_per_valu_instr": (prof.get("derived") or {}).get("simd_cycles_per_valu_instr")}
+        return out
+    except Exception as e:
+        sys.stderr.write(f"[bench] mix ceiling of the mul kernel unavailable: {e}\n")
+        return None
 
 
 def leg_cu_endo(args, dev_index):

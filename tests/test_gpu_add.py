@@ -123,6 +123,34 @@ def test_sparse_bloom_false_positives_and_continuation():
     assert len(lines) == g["count"] and orc.digest(lines) == g["sha256_sorted"]
 
 
+def test_automatic_geometry_of_short_calls():
+    """no geometry set: the library picks the half group by its cost model (ecloop_hip.hip: auto_half_group - 8 for the reference's 2^21-key
+    job, 16 / 32 for 2^22 ... 2^25, up to 1024 for 2^32).  The reference's golden false-positive set over two 2^21-key jobs as two
+    contiguous calls (the second continues the resident walk: no second set-up), then call sizes from one group to 2^22 keys against
+    the oracle, contiguous continuation across a change of size included."""
+    from ecloop_amd import Device
+    g = G["sparse_fp33_two_jobs"]
+    words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])
+    d = Device(0)
+    try:
+        d.set_bloom(words)
+        r1, n1 = d.add_range(0x8000, 1 << 21, cap=4096)
+        r2, n2 = d.add_range(0x8000 + (1 << 21), 1 << 21, cap=4096)
+        assert d.timing()[1] == 2 and d.setup_timing()[1] == 1  # two launches, one positioning
+        lines = sorted(lines_of(r1, 0x8000) + lines_of(r2, 0x8000 + (1 << 21)))
+        assert len(lines) == g["count"] and orc.digest(lines) == g["sha256_sorted"]
+        flt = orc.OrcFilter(bloom_words=words)
+        at = 0x123456789A
+        for nkeys in (2048, 4096, 1 << 14, 3 << 15, 1 << 17, 5 << 17, 1 << 20, 1 << 22, 1 << 19):
+            recs, n = d.add_range(at, nkeys, cap=1 << 16)
+            rc, out, cnt, _, hashed = orc.add_range(flt, at, at + nkeys, verify=False, threads=8, cap=1 << 16)
+            assert rc == 0 and hashed == nkeys and n == cnt
+            assert sorted(lines_of(recs, at)) == sorted(orc.found_lines(out, cnt)), nkeys
+            at += nkeys
+    finally:
+        d.close()
+
+
 def test_dense_bloom_cu_endo_false_positives():
     g = G["dense_fp_cu_endo"]
     words = synth_bloom_words(g["bloom"]["words"], g["bloom"]["seed"], g["bloom"]["mode"])

@@ -5,11 +5,11 @@
 # Counter passes are separate runs with --kernel-trace only (never --pmc together with sys/hip/hsa tracing), one
 # 2^32-key launch each (ECL_HIP_SKIP_SELFTEST=1: no 4096-key self-test launch in the counters).
 # Copy what is to be kept into profiles/ (tracked); bench.py reads profiles/<tag>_roofline.json.
-#   PARTS="ubench headline calib mul cu_endo bench" (default: all) selects what is collected; a part that is left out keeps
+#   PARTS="ubench headline calib mul cu_endo bench parity" (default: all) selects what is collected; a part that is left out keeps
 #   whatever profiles/ already holds for it
 set -u
-TAG=${1:-r04}
-PARTS=${PARTS:-ubench headline calib mul cu_endo bench}
+TAG=${1:-r05}
+PARTS=${PARTS:-ubench headline calib mul cu_endo bench parity}
 want() { [[ " $PARTS " == *" $1 "* ]]; }
 export TMPDIR=/tmp
 R=$(pwd)
@@ -50,6 +50,17 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         if pat not in r["Kernel_Name"]: continue
         print("TRACE %s %d" % (r["Kernel_Name"].split("(")[0][:60].replace(" ", ""), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+if os.environ.get("SUMM_PER_DISPATCH"):  # one row per dispatch as well (time-weighted ratios over the full-size pieces of `mul`)
+    per = collections.defaultdict(dict); ns = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]:
+                i = int(r["Dispatch_Id"]); per[i][r["Counter_Name"]] = per[i].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat in r["Kernel_Name"]: ns[int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    for i in sorted(per):
+        for c, v in sorted(per[i].items()): print("DISPATCH %d %d %s %.0f" % (i, ns.get(i, 0), c, v))
 PY
 }
 
@@ -93,9 +104,11 @@ if want mul; then
 for set in "SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "VALUBusy"; do
   ECL_HIP_SKIP_SELFTEST=1 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$O/pmcm" -o p -- python "$R/bench.py" --cmd mul --steps 1 --warmup 1 > "$O/pmcm.log" 2>&1
   echo "# --pmc $set   (bench.py --cmd mul --steps 1 --warmup 1: 3 x 2^24 scalars, -a cu, 26-bit window table)" >> "$O/pmc_mul.txt"
-  summ "$O/pmcm" k_mul >> "$O/pmc_mul.txt"
+  SUMM_PER_DISPATCH=1 summ "$O/pmcm" k_mul >> "$O/pmc_mul.txt"
   rm -rf "$O/pmcm"
 done
+# where the kernel's issue slots go: wait / TCP / translation counters per dispatch, full-size pieces only, W = 22 and 26
+( cd "$R" && python tools/mul_stall_profile.py --tag "$TAG" > "$O/mul_stall.log" 2>&1 && cp "gpurun_out/${TAG}_mul_stall.txt" "profiles/${TAG}_mul_stall.txt" )
 fi
 
 # the -a cu -endo kernel (configs[2]'s per-GPU shape): one 2^30-key launch against the 5.9 GB filter
@@ -127,6 +140,18 @@ if want bench; then
   python bench.py > "$O/bench.json" 2> "$O/bench.err"
   cp "$O/bench.json" "profiles/${TAG}_bench.json"
   cat "$O/bench.json"
+fi
+# bit-exact found lists against the reference binary on the final build: the whole 2^32-key range of the headline config (54 MB filter)
+# and -a cu -endo over 2^28 keys against the 5.9 GB filter (two runs of tools/full_range_parity.py), both binaries reading the same .blf
+if want parity; then
+  { echo "# tools/collect_profiles.sh $TAG, last step: found lists of the HIP path and of the unmodified reference binary (oracle/_ref/ecloop_sane, built from"
+    echo "# /root/reference/main.c by oracle/Makefile) on identical private-key ranges, same .blf file.  source_sha256 $(python -c 'from ecloop_amd.build import source_sha256; print(source_sha256())')"
+    python tools/full_range_parity.py --endo-log2 24 2> "$O/parity1.err"; echo "exit code $?"
+    echo
+    python tools/full_range_parity.py --filter-n 1100000000 --main-log2 28 --endo-log2 28 2> "$O/parity2.err"; echo "exit code $?"
+  } > "$O/full_range_parity.txt"
+  cp "$O/full_range_parity.txt" "profiles/${TAG}_full_range_parity.txt"
+  grep -E "^(==|HIP|reference|identical|exit)" "$O/full_range_parity.txt"
 fi
 [ -f "$O/stats.txt" ] && head -8 "$O/stats.txt"
 cat "$O"/pmc*.txt 2>/dev/null | grep -v TRACE | head -80; cat "$O/make_profile.err"
