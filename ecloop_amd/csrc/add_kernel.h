@@ -228,41 +228,11 @@ __device__ __forceinline__ void filter_check(const add_args& a, cand_queues* q, 
   cand_push(a, q, pass, off, h, endo | (compressed << 8));
 }
 
-// ---- stage-1 probe deferred by one hash (ECL_DEFER_PROBE=1, A/B builds) ----------------------------------------
-// The probe of hash k is issued right after hash k is computed but tested only after hash k+1: its (random-sector) load
-// is in flight under ~2200 instructions of the next hash instead of being waited for on the spot.  Costs ~11 VGPRs held
-// across the hash (loaded word, bit, offset, hash160, tag).  Same probes, same order per hash: identical results.
-#ifndef ECL_DEFER_PROBE
-#define ECL_DEFER_PROBE 0
-#endif
-struct probe_pending {
-  u64 word, off;
-  u32 h[5], tag, bit;
-  bool live;
-};
-__device__ __forceinline__ void filter_check_deferred(const add_args& a, cand_queues* q, probe_pending& pend, bool live, u64 off,
-                                                      const u32 h[5], u32 endo, u32 compressed) {
-  u64 aw[5];
-  bloom_words_of(aw, h);
-  const u64 idx = bloom_index(aw, 0);
-  const u64 word = a.bloom.bits[bloom_mod(a.bloom, idx >> 6)];  // issued now, first used one hash later
-  const bool pass = pend.live && ((pend.word >> pend.bit) & 1);
-  cand_push(a, q, pass, pend.off, pend.h, pend.tag);
-  pend.word = word, pend.off = off, pend.tag = endo | (compressed << 8), pend.bit = (u32)idx & 63u, pend.live = live;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) pend.h[i] = h[i];
-}
-__device__ __forceinline__ void filter_flush_deferred(const add_args& a, cand_queues* q, probe_pending& pend) {
-  const bool pass = pend.live && ((pend.word >> pend.bit) & 1);
-  cand_push(a, q, pass, pend.off, pend.h, pend.tag);
-  pend.live = false;
-}
-
 // hash every selected encoding / endomorphism image of the affine point (x, y) and probe the filter
 // (check_found_add, main.c:287-347; endo images (x,-y) (bx,y) (bx,-y) (b2x,y) (b2x,-y), main.c:314-327).
 // x: magnitude <= 4, y: magnitude <= 3.
 template <bool A33, bool A65, bool ENDO>
-__device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, bool live, fe x, fe y, u64 off, probe_pending* pend = nullptr) {
+__device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, bool live, fe x, fe y, u64 off) {
   u32 xw[3][8], yw[2][8], par = 0;
   if (ENDO) {
     const u32 bw[8] = FE_BETA1_W;
@@ -295,16 +265,14 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, b
     for (int i = 0; i < 8; ++i) xs[i] = ENDO ? (e < 2 ? xw[0][i] : (e < 4 ? xw[1][i] : xw[2][i])) : xw[0][i];
     if (A33) {
       hash160_33(h, xs, (par ^ (u32)e) & 1u);  // parity(-y) = !parity(y): p is odd, y != 0
-      if (ECL_DEFER_PROBE && pend) filter_check_deferred(a, q, *pend, live, off, h, e, 1);
-      else filter_check(a, q, live, off, h, e, 1);
+      filter_check(a, q, live, off, h, e, 1);
     }
     if (A65) {
       u32 ys[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) ys[i] = (ENDO && (e & 1)) ? yw[1][i] : yw[0][i];
       hash160_65(h, xs, ys);
-      if (ECL_DEFER_PROBE && pend) filter_check_deferred(a, q, *pend, live, off, h, e, 0);
-      else filter_check(a, q, live, off, h, e, 0);
+      filter_check(a, q, live, off, h, e, 0);
     }
   }
 }
@@ -333,12 +301,6 @@ __global__ void __launch_bounds__(ECL_ADD_BLOCK, (A33 && A65 && ENDO) ? 3 : ECL_
   const u32 g = blockIdx.x * (u32)ECL_ADD_BLOCK + threadIdx.x;
   const u32 T = a.T, B = a.B;
   if (g >= T) return;
-#if ECL_DEFER_PROBE
-  probe_pending pend;
-  pend.live = false, pend.word = 0, pend.off = 0, pend.tag = 0, pend.bit = 0;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) pend.h[i] = 0;
-#endif
   const size_t plane = T;
   // centre (X, Y): canonical in HBM, magnitude 1 in registers
   fe X = fe_ld_words2(a.cxy + g, plane), Y = fe_ld_words2(a.cxy + 2 * (size_t)T + g, plane);
@@ -416,11 +378,7 @@ __global__ void __launch_bounds__(ECL_ADD_BLOCK, (A33 && A65 && ENDO) ? 3 : ECL_
             FE_HIDE24(py.n[l]);
           }
         }
-#if ECL_DEFER_PROBE
-        if (valid) check_point<A33, A65, ENDO>(a, &q, off < a.nkeys, px, py, off, &pend);
-#else
         if (valid) check_point<A33, A65, ENDO>(a, &q, off < a.nkeys, px, py, off);
-#endif
       }
 #if ECL_PREFETCH
       pre = nxt;
@@ -440,9 +398,6 @@ __global__ void __launch_bounds__(ECL_ADD_BLOCK, (A33 && A65 && ENDO) ? 3 : ECL_
     fe_normalize_weak(Yn);
     X = Xn, Y = Yn;
   }
-#if ECL_DEFER_PROBE
-  filter_flush_deferred(a, &q, pend);
-#endif
   cand_flush(a, q);
   fe_st_words2(a.cxy + g, plane, X);
   fe_st_words2(a.cxy + 2 * (size_t)T + g, plane, Y);

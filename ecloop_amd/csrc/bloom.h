@@ -87,31 +87,10 @@ FE_FN void bloom_words_of(u64 a[5], const u32 h[5]) {
 #ifndef ECL_STAGE1_PROBES
 #define ECL_STAGE1_PROBES 1
 #endif
-// ECL_PROBE_QUARTER (A/B builds, round 4): for filters beyond the Infinity Cache the stage-1 load is issued as four instructions
-// of 16 active lanes each (one quarter of the wave at a time) instead of one of 64 - 16 instead of 64 L1 misses per instruction
-// in the vector L1's miss path, where the 5.9 GB filter's probes queue (profiles/r03_pmc_filter_compare.txt).
-#ifndef ECL_PROBE_QUARTER
-#define ECL_PROBE_QUARTER 0
-#endif
+// (Issuing this probe as four instructions of 16 active lanes for multi-GB filters was built and rejected in round 4: -1.3 %, HISTORY.md.)
 FE_FN bool bloom_stage1(const bloom_t& b, const u32 h[5]) {
   u64 a[5];
   bloom_words_of(a, h);
-#if defined(__HIP_DEVICE_COMPILE__) && ECL_PROBE_QUARTER
-  if (b.nwords >= (1ull << 24)) {
-    const u64 idx = bloom_index(a, 0);
-    const u64 wi = bloom_mod(b, idx >> 6);
-    const u32 quarter = (threadIdx.x >> 4) & 3u;
-    u64 word = 0;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k)
-      if (quarter == k) {
-        u64 t = wi;
-        asm volatile("" : "+v"(t));  // four loads, not one: keep the compiler from merging the identical address expressions
-        word = b.bits[t];
-      }
-    return (word >> (idx & 63)) & 1;
-  }
-#endif
   bool p0 = bloom_bit(b, bloom_index(a, 0));
 #if ECL_STAGE1_PROBES == 2
   bool p1 = bloom_bit(b, bloom_index(a, 1));

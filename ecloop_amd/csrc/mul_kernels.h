@@ -181,12 +181,7 @@ __global__ void k_gather_slots(const u32* __restrict__ table, const u64* __restr
 // sums stay Jacobian and are parked in `tmp` (planes of nt words: X, Y, Z and the running product of the Z's, 144 bytes
 // per scalar) until ONE inversion per thread turns them all affine (Montgomery's trick, as ec_jacobi_grprdc does for
 // the reference's 2048-key job): 11 multiplications per non-zero digit + 17 + 7 per scalar instead of 209 + 270 + 3.
-#ifndef ECL_MUL_LDS_GATHER
-#define ECL_MUL_LDS_GATHER 1  /* the next window's table point travels HBM -> LDS (global_load_lds_dwordx4 into the wave's idle candidate-ring memory)
-                                 instead of HBM -> 16 VGPRs held across an addition; A/B: 0 = the register form of round 4 (see wtab_sum_fast) */
-#endif
-__device__ __forceinline__ xyzz wtab_sum_fast(const u32* kw, const wtab t, u32& bad, u32* stage, u32* stage2, bool& pref, const u32* kw_next);
-__device__ __forceinline__ void wtab_stage_scalar(const u32* __restrict__ kw, u32* slot);
+__device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad);
 #define MUL_R 32u  /* at most (one bit of `infmask` each); short pieces take fewer per thread so that the chip still fills (ecl_hip_mul_batch) */
 #ifndef ECL_MUL_WAVES
 #define ECL_MUL_WAVES 3  /* waves per SIMD the register allocator leaves room for (256-thread blocks: blocks per CU); the host side launches
@@ -197,37 +192,18 @@ __device__ __forceinline__ void wtab_stage_scalar(const u32* __restrict__ kw, u3
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
-  // per wave 3 x 4 KiB: the two candidate rings of the walk back (add_kernel.h) in [0] and [1]; before it, while the window sums run, all
-  // three stage what is on its way from HBM (48 KB per workgroup: three workgroups per CU = 144 of the 160 KB)
-  __shared__ u32 q_mem[4][3][8 * ECL_Q_SLOTS];
+  __shared__ u32 q_mem[4][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave (add_kernel.h)
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt) return;  // nt is a multiple of 256: whole workgroups leave
   fe prod = fe_one();
   u32 infmask = 0;
-  // the rings are idle until the walk back: ring A's 4 KiB stage the next window's table point, ring B's hold the wave's scalars of this
-  // round and of the next (two slots of 2 KiB), which arrive one round ahead
-  u32* const stage = q_mem[threadIdx.x >> 6][0];
-  u32* const kst = q_mem[threadIdx.x >> 6][1];
-  u32* const stage2 = q_mem[threadIdx.x >> 6][2];
-  bool pref = false;  // wave-uniform: the first two table points of this round's scalars were requested during the round before
-  if (t < n) wtab_stage_scalar(k + (size_t)t * 8, kst);
   // parked per scalar: X * ZZZ, Y * ZZ, T = ZZ * ZZZ and the running product of the T's; x = X ZZZ / T, y = Y ZZ / T
 #pragma unroll 1
   for (u32 r = 0; r < R; ++r) {
     const u32 i = r * nt + t;
     if (i >= n) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first scalar has to be waited for; the later ones land during the round before
-#endif
-    const bool have_next = r + 1u < R && i + nt < n;
-    if (have_next) wtab_stage_scalar(k + (size_t)(i + nt) * 8, kst + 512u * ((r + 1u) & 1u));
     u32 bad;
-    xyzz acc = wtab_sum_fast(kst + 512u * (r & 1u), gtab, bad, stage, stage2, pref, have_next ? kst + 512u * ((r + 1u) & 1u) : nullptr);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the next round's scalar was requested a whole window sum ago and nothing else is in flight here: this wait is free, and it stands in
-    // front of the parking stores below, which the wait at the head of the next round would otherwise have to sit out
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    xyzz acc = wtab_sum_fast(k + (size_t)i * 8, gtab, bad);
     acc.inf = 0;
     // a zero digit (stand-in point), or P = +-Q on the way (h = 0: only scalars that are 0 (mod n) or built around n) which leaves ZZ = 0 -
     // and a zero in the product chain would take the thread's other scalars with it: the complete sum, out of line
@@ -294,46 +270,19 @@ __device__ __forceinline__ u32 wtab_digit_mem(const u32* __restrict__ kw, const 
   __builtin_memcpy(&v, kw + word, 8);  // an 8-byte load from a 4-byte aligned address (odd `word`): one global_load_dwordx2 on gfx950
   return (u32)(v >> sh) & t.per;  // raw digit
 }
-// ... and from the scalar's copy in LDS (round 5).  The digit loads used to go to the scalar in global memory, four instructions in front of
-// their use: an L1 hit in a quiet cache, but the 64-byte gathers of twelve waves turn the CU's 32 KB of L1 over every few microseconds, so
-// each window waited for an L2 / HBM round trip.  A wave's scalars now arrive in LDS one scalar ahead (two global_load_lds_dwordx4 per
-// scalar: plane 0 = words 0..3, plane 1 = words 4..7, lane l's four words at 16 l) and a digit is two ds_read_b32.
-__device__ __forceinline__ void wtab_stage_scalar(const u32* __restrict__ kw, u32* slot) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kw, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kw + 4), (__attribute__((address_space(3))) void*)(slot + 256), 16, 0, 0);
-#else
-  (void)kw, (void)slot;
-#endif
-}
-__device__ __forceinline__ u32 wtab_digit_lds(const u32* slot, const wtab& t, u32 w) {
-  u32 bit = w * t.W, word = bit >> 5, sh = bit & 31u;
-  if (word > 6u) word = 6u, sh += 32u;
-  const u32 lane4 = 4u * (threadIdx.x & 63u);
-  const u32 lo = slot[256u * (word >> 2) + lane4 + (word & 3u)], hi = slot[256u * ((word + 1u) >> 2) + lane4 + ((word + 1u) & 3u)];
-  return (u32)((((u64)hi << 32) | lo) >> sh) & t.per;
-}
 #ifndef ECL_MUL_HOT_GATHERS
-#define ECL_MUL_HOT_GATHERS 0  /* MEASUREMENT BUILD ONLY (wrong points): every gather lands in the first 256 slots of its row, i.e. in cache -
-                                  the same instructions and loads with the table's latency taken away: the upper bound of what ANY deeper
-                                  prefetch of the table points (more registers, LDS staging two windows ahead) could gain; tools/ab_r05b.sh */
+#define ECL_MUL_HOT_GATHERS 0  /* MEASUREMENT BUILD ONLY (wrong points): every gather lands in the first 256 slots of its row, i.e. in cache - the same
+                                  instructions and loads without the table's HBM traffic (tools/ab_r05b.sh, tools/ab_r05c.sh) */
 #endif
-// One table point (64 bytes per lane) from HBM into the wave's staging area in LDS without touching a vector register: four
-// global_load_lds_dwordx4, each writing lane l's 16 bytes at (wave-uniform base in M0) + 16 l - plane j of the 4 KiB area holds words
-// 4 j .. 4 j + 3 of every lane's point - and back out by four ds_read_b128 when the point is added.  The compiler counts these loads
-// in vmcnt like any other and waits for them in front of the LDS reads.
-__device__ __forceinline__ void wtab_stage_point(const u32* __restrict__ e, u32* stage) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(e + 4 * j), (__attribute__((address_space(3))) void*)(stage + 256 * j), 16, 0, 0);
-#else
-  (void)e, (void)stage;
-#endif
-}
-// kw: the scalar's copy in LDS (wtab_stage_scalar); stage / stage2: 4 KiB each (wtab_stage_point); pref (in): the points of windows 0 and 1
-// are in stage / stage2 already, (out): those of the NEXT scalar (kw_next, nullptr for a lane that has none) have been requested
-__device__ __forceinline__ xyzz wtab_sum_fast(const u32* kw, const wtab t, u32& bad, u32* stage, u32* stage2, bool& pref, const u32* kw_next) {
+// How the table points reach the additions, and what was measured about it in round 5 (profiles/r05_mul_lds_gather.txt, commit be22f1e):
+// the point of window w + 1 is requested in the middle of window w's addition and held in 16 VGPRs.  Three deeper forms were built - the
+// point staged in LDS by global_load_lds_dwordx4 (no register held), the wave's scalars staged in LDS a round ahead (digits by ds_read
+// instead of a global load four instructions before its use), the first two points of the next scalar requested during the last addition
+// of this one - and all ran within 0.5 % of this form (1272-1279 M scalars/s on 2^24-scalar calls): at three waves per SIMD another wave
+// issues while one waits.  The build with cache-resident gathers is 11-13 % faster, but through the CLOCK (2.26 against 2.06 GHz; wait
+// share and clocks per instruction unchanged): the kernel runs against the board's power limit, and 0.9 TB/s of random 64-byte HBM
+// reads take watts from the shader clock.  Fewer HBM bytes per scalar would help; hiding their latency does not.
+__device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const wtab t, u32& bad) {
   // Windows that hold a zero digit in EVERY lane of the wave are not walked at all: the loop ends at the highest window in which some
   // lane has something to add (round 5).  That is what small scalars need - puzzle-range or sequential keys: all of their high windows,
   // which the reference skips one by one (lib/ecc.c:913) and which used to send every such scalar through the complete sum - and it
@@ -342,7 +291,7 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* kw, const wtab t, u32& 
   u32 nw = t.nwin;
 #if defined(__HIP_DEVICE_COMPILE__)
   {
-    const uint4 k0 = ((const uint4*)kw)[threadIdx.x & 63u], k1 = ((const uint4*)(kw + 256))[threadIdx.x & 63u];
+    const uint4 k0 = ((const uint4*)kw)[0], k1 = ((const uint4*)kw)[1];  // (the scalar's own cache line: the digit loads below hit it)
     const u32 ws[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
     u32 bits = 0;
 #pragma unroll
@@ -351,61 +300,34 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* kw, const wtab t, u32& 
   }
 #endif
   u32 carry = 0, s0, s1, sn = 0;
-  u32 d0 = wtab_recode(t, 0, wtab_digit_lds(kw, t, 0), carry, s0), d1 = wtab_recode(t, 1, wtab_digit_lds(kw, t, 1), carry, s1);
-  u32 dn = nw > 2u ? wtab_recode(t, 2, wtab_digit_lds(kw, t, 2), carry, sn) : 1u;
+  u32 d0 = wtab_recode(t, 0, wtab_digit_mem(kw, t, 0), carry, s0), d1 = wtab_recode(t, 1, wtab_digit_mem(kw, t, 1), carry, s1);
+  u32 dn = nw > 2u ? wtab_recode(t, 2, wtab_digit_mem(kw, t, 2), carry, sn) : 1u;
   bad = (d0 == 0u) | (d1 == 0u);
   d0 = d0 ? d0 : 1u, d1 = d1 ? d1 : 1u;
   if (ECL_MUL_HOT_GATHERS) d0 = (d0 & 255u) + 1u, d1 = (d1 & 255u) + 1u;
-  // The first two points.  Round 4 fetched them here, in front of their use - an HBM round trip per scalar that the other two waves of the
-  // SIMD cover only in part; now the wave asks for them while it adds the last point of the scalar before (end of the loop below) and
-  // finds them in LDS.  Only a wave's first scalar, and the one after a scalar whose loop did not run, still fetch them in place.
-  const uint4* st4 = (const uint4*)stage + (threadIdx.x & 63u);
-  const uint4* st4b = (const uint4*)stage2 + (threadIdx.x & 63u);
-  if (!pref) {  // (wave-uniform) through the same staging areas, so that there is one way the points are read
-    wtab_stage_point(t.p + ((size_t)d0 - 1) * 16, stage);
-    wtab_stage_point(t.p + ((size_t)t.stride + d1 - 1) * 16, stage2);
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  }  // else: landed - the caller waited for them in front of the parking stores of the round before
-  const uint4 a0 = st4[0], a1 = st4[64], a2 = st4[128], a3 = st4[192], b0 = st4b[0], b1 = st4b[64], b2 = st4b[128], b3 = st4b[192];
-  // The point of window w + 1 is requested in the middle of window w's addition and waits in LDS (ECL_MUL_LDS_GATHER; round 4 kept it in 16
-  // VGPRs across the rest of the addition), window 2's right here, before the first addition.
+  xyzz acc;
+  {
+    const uint4* e0 = (const uint4*)(t.p + ((size_t)d0 - 1) * 16);
+    const uint4* e1 = (const uint4*)(t.p + ((size_t)t.stride + d1 - 1) * 16);
+    const uint4 a0 = e0[0], a1 = e0[1], a2 = e0[2], a3 = e0[3], b0 = e1[0], b1 = e1[1], b2 = e1[2], b3 = e1[3];
+    const u32 pxw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pyw[8] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+    const u32 qxw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, qyw[8] = {b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_cneg_weak(fe_from_words(pyw), s0), fe_from_words(qxw), fe_cneg_weak(fe_from_words(qyw), s1));
+  }
   uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
   if (nw > 2u) {
     bad |= dn == 0u;
     dn = dn ? dn : 1u;
     if (ECL_MUL_HOT_GATHERS) dn = (dn & 255u) + 1u;
-    const u32* e = t.p + ((size_t)2 * t.stride + dn - 1) * 16;
-    if (ECL_MUL_LDS_GATHER) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the staged first point has been read out of this area)
-#endif
-      wtab_stage_point(e, stage);
-    } else n0 = ((const uint4*)e)[0], n1 = ((const uint4*)e)[1], n2 = ((const uint4*)e)[2], n3 = ((const uint4*)e)[3];
+    const uint4* e = (const uint4*)(t.p + ((size_t)2 * t.stride + dn - 1) * 16);
+    n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
   }
-  xyzz acc;
-  {
-    const u32 pxw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, pyw[8] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-    const u32 qxw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, qyw[8] = {b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    acc = xyzz_mmadd_lazy(fe_from_words(pxw), fe_cneg_weak(fe_from_words(pyw), s0), fe_from_words(qxw), fe_cneg_weak(fe_from_words(qyw), s1));
-  }
-  pref = false;
 #pragma unroll 1
   for (u32 w = 2; w < nw; ++w) {
-    if (ECL_MUL_LDS_GATHER) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      // the staged point must have landed before LDS is read.  hipcc (ROCm 7.2) counts the LDS-DMA loads in vmcnt but does NOT wait for them in
-      // front of these reads here (it does in small kernels; seen in the assembly of this one: ds_read_b128 at the loop head with the four
-      // global_load_lds of the iteration before still uncounted) - so the wait is written out.  Nothing else is in flight at this point.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-      n0 = st4[0], n1 = st4[64], n2 = st4[128], n3 = st4[192];
-    }
     const u32 xw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w}, yw[8] = {n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
     const bool more = w + 1u < nw;
     const u32 neg = sn;
-    dn = more ? wtab_recode(t, w + 1u, wtab_digit_lds(kw, t, w + 1u), carry, sn) : 1u;
+    dn = more ? wtab_recode(t, w + 1u, wtab_digit_mem(kw, t, w + 1u), carry, sn) : 1u;
     fe u2, s2p;  // (the ten operations of an addition as five interleaved pairs: +0.5-1 %, profiles/r04_mul_pairs.txt)
     fe_mul_pair(u2, s2p, fe_from_words(xw), acc.ZZ, fe_from_words(yw), acc.ZZZ);
     const fe s2m = fe_neg(s2p, 1);
@@ -413,28 +335,8 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* kw, const wtab t, u32& 
       bad |= dn == 0u;
       dn = dn ? dn : 1u;
       if (ECL_MUL_HOT_GATHERS) dn = (dn & 255u) + 1u;
-      const u32* e = t.p + ((size_t)(w + 1u) * t.stride + dn - 1) * 16;
-      if (ECL_MUL_LDS_GATHER) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and this window's point has left the staging area before the next one is written over it
-#endif
-        wtab_stage_point(e, stage);
-      } else n0 = ((const uint4*)e)[0], n1 = ((const uint4*)e)[1], n2 = ((const uint4*)e)[2], n3 = ((const uint4*)e)[3];
-    } else if (ECL_MUL_LDS_GATHER) {
-      // the last window of this scalar: the staging areas are free - ask for the first two points of the wave's next scalars (their words
-      // came into LDS during this sum; every loop-head wait above has been behind them)
-      pref = true;
-      if (kw_next) {
-        u32 c2 = 0, sg;
-        u32 e0 = wtab_recode(t, 0, wtab_digit_lds(kw_next, t, 0), c2, sg), e1 = wtab_recode(t, 1, wtab_digit_lds(kw_next, t, 1), c2, sg);
-        e0 = e0 ? e0 : 1u, e1 = e1 ? e1 : 1u;
-        if (ECL_MUL_HOT_GATHERS) e0 = (e0 & 255u) + 1u, e1 = (e1 & 255u) + 1u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        wtab_stage_point(t.p + ((size_t)e0 - 1) * 16, stage);
-        wtab_stage_point(t.p + ((size_t)t.stride + e1 - 1) * 16, stage2);
-      }
+      const uint4* e = (const uint4*)(t.p + ((size_t)(w + 1u) * t.stride + dn - 1) * 16);
+      n0 = e[0], n1 = e[1], n2 = e[2], n3 = e[3];
     }
     fe s2;
 #pragma unroll
