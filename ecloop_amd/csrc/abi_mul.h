@@ -265,7 +265,7 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   if ((rc = mul_setup_auto(h, n, &W)) != ECL_OK) return rc;
   const wtab gtab = wtab_make(h->d_multab, W);
   h->mul_seen += n;
-  // Scalars in page-locked host memory (ecl_hip_alloc_host / ecl_hip_pin_host) go to the device by DMA straight from the
+  // Scalars in page-locked host memory (ecl_hip_alloc_host) go to the device by DMA straight from the
   // caller's array; pageable ones are first copied into two pinned staging buffers - a single-threaded memcpy that caps
   // the call near 18 GB/s = 570 M scalars/s (measured), below what the kernel takes.
   bool direct = false;
@@ -273,8 +273,14 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
     hipPointerAttribute_t attr;
     memset(&attr, 0, sizeof attr);
     if ((size_t)n * 32 >= ECL_PIN_MIN_BYTES) {  // small batches are staged whatever their memory is
+      // page-locked from the first byte to the last (memory from ecl_hip_alloc_host, or registered by the caller itself)
       if (hipPointerGetAttributes(&attr, scalars) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
       else (void)hipGetLastError();
+      if (direct) {
+        memset(&attr, 0, sizeof attr);
+        if (hipPointerGetAttributes(&attr, (const char*)scalars + (size_t)n * 32 - 1) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError(), direct = false;
+      }
     }
   }
   if (!direct && (!h->pin_k[0] || h->pin_cap < h->kbuf_cap)) {

@@ -191,25 +191,18 @@ int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
   return ECL_OK;
 }
 
-// Page-locking works on whole pages.  A small buffer shares its pages with whatever else the host allocator put there,
-// and registering / unregistering such a page under other host buffers that the runtime copies from or to ended in GPU
-// memory access faults on host heap addresses (tools/fuzz_mul_gpu.py, round 2: always a few calls after a 64-byte or
-// 2 KB array had been pinned).  Buffers below 1 MiB are therefore left alone - they gain nothing from DMA anyway - and
-// the pair of calls stays symmetric through a registry of what was really registered.
-#define ECL_PIN_MIN_BYTES ((size_t)1 << 20)
-static std::mutex g_pin_mu;
-static std::set<const void*> g_pinned;
-int ecl_hip_pin_host(const void* p, size_t bytes) {
-  if (!p || !bytes) return ECL_E_ARG;
-  if (bytes < ECL_PIN_MIN_BYTES) return ECL_OK;
-  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
-    (void)hipGetLastError();
-    return ECL_E_HIP;
-  }
-  std::lock_guard<std::mutex> lk(g_pin_mu);
-  g_pinned.insert(p);
-  return ECL_OK;
-}
+// Page-locking caller memory in place (hipHostRegister) was what these two calls did until round 5; now they accept the buffer and do
+// nothing.  Registering and unregistering memory that the host allocator recycles - next to, or later as, the source or destination of
+// the runtime's own pageable copies, which pin on the fly and remember what they pinned - ends in GPU memory access faults on heap
+// addresses: round 2 saw it a few calls after a 64-byte or 2 KB array had been pinned (small buffers were then left alone), round 5 once
+// in ~2000 fuzz trials with arrays of megabytes, and tools/repro_pin_fault.py gets it within seconds from register / copy / unregister /
+// free cycles, whether the whole buffer or only its whole pages are registered, whether or not the GPU ever reads it - and never
+// without the registration (5000 rounds).  Keeping the ranges registered for good instead made later copies of recycled memory that
+// straddle such a range fail.  Page-locked memory therefore comes from the runtime (ecl_hip_alloc_host = hipHostMalloc, next to the GPU's
+// NUMA node); pageable buffers are copied by the runtime (filter: at the same rate for 54 MB, profiles/r02_bringup.txt) or staged
+// through the library's own pinned buffers (scalar arrays of ecl_hip_mul_batch).
+#define ECL_PIN_MIN_BYTES ((size_t)1 << 20)  /* ecl_hip_mul_batch: batches below this are staged whatever their memory is */
+int ecl_hip_pin_host(const void* p, size_t bytes) { return p && bytes ? ECL_OK : ECL_E_ARG; }
 void* ecl_hip_alloc_host(size_t bytes) {
   void* p = nullptr;
   if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
@@ -218,14 +211,7 @@ void* ecl_hip_alloc_host(size_t bytes) {
 void ecl_hip_free_host(void* p) {
   if (p) (void)hipHostFree(p);
 }
-int ecl_hip_unpin_host(const void* p) {
-  if (!p) return ECL_E_ARG;
-  {
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    if (!g_pinned.erase(p)) return ECL_OK;  // never registered (too small): nothing to undo
-  }
-  return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? ECL_OK : ECL_E_HIP;
-}
+int ecl_hip_unpin_host(const void* p) { return p ? ECL_OK : ECL_E_ARG; }
 
 int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
   if (!h || (n && !h160)) return ECL_E_ARG;

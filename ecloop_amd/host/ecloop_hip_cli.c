@@ -70,7 +70,7 @@ static int context_devices(int cmd, int shown, int real, int dev_of[MAX_GPUS]) {
   for (int g = 0; g < n; ++g) dev_of[g] = (g % shown) % real;
   return n;
 }
-/* one context: open (self-test once per process), filter upload from the one pinned host copy, optional list, walk
+/* one context: open (self-test once per process), filter upload from the one host copy, optional list, walk
    buffers of the largest chunk this run will hand out; every step timed for ECLOOP_HIP_STATS */
 typedef struct { run_t *run; int g, device; u32 flags; u64 reserve_keys; int rc; u64 t[5]; } bringup_t;
 static void *bringup_thread(void *arg) {
@@ -98,7 +98,6 @@ static double bring_up(run_t *run, int shown, int real) {
   const u64 t0 = ms_now();
   int dev_of[MAX_GPUS];
   run->ngpus = context_devices(run->cmd, shown, real, dev_of);
-  const bool pinned = run->flt.nwords >= (8u << 20) && ecl_hip_pin_host(run->flt.words, run->flt.nwords * 8) == ECL_OK;
   u64 largest_call = 0;
   if (run->cmd != CMD_MUL) { /* keys of the largest device call: see scan_chunk() */
     sc keys;
@@ -131,7 +130,6 @@ static double bring_up(run_t *run, int shown, int real) {
       printf("gpu %d bring-up: open %.1f ms, filter upload %.1f ms, list %.1f ms, reserve(%llu keys) %.1f ms\n", g,
              (job[g].t[1] - job[g].t[0]) / 1e3, (job[g].t[2] - job[g].t[1]) / 1e3, (job[g].t[3] - job[g].t[2]) / 1e3,
              (unsigned long long)largest_call, (job[g].t[4] - job[g].t[3]) / 1e3);
-  if (pinned) ecl_hip_unpin_host(run->flt.words);
   return (ms_now() - t0) / 1000.0;
 }
 

@@ -77,18 +77,15 @@ void ecl_hip_close(ecl_hip *h);
    filter built from a hash list, utils.c:277-280) into HBM.  May be called again to replace the filter. */
 int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 
-/* Optional: page-lock a host buffer (e.g. the bits about to be given to ecl_hip_set_bloom on several devices) so that
-   the uploads run by DMA at PCIe rate, concurrently from one buffer; undo with ecl_hip_unpin_host.  Thin wrappers of
-   hipHostRegister / hipHostUnregister so that a plain-C host needs no HIP headers.
-   Buffers below 1 MiB are accepted and left unpinned (page-locking acts on whole pages, which a small buffer shares with
-   unrelated host data); unpinning them is a no-op. */
+/* Kept for callers written against earlier versions: accepted, and nothing is done.  They used to page-lock the caller's buffer in
+   place (hipHostRegister / hipHostUnregister); register / unregister cycles on memory that the host allocator recycles fault inside the
+   ROCm runtime (tools/repro_pin_fault.py; csrc/ecloop_hip.hip has the account).  Page-locked memory comes from ecl_hip_alloc_host. */
 int ecl_hip_pin_host(const void *p, size_t bytes);
 int ecl_hip_unpin_host(const void *p);
-/* ... or get page-locked host memory to begin with (hipHostMalloc / hipHostFree): scalar arrays given to
-   ecl_hip_mul_batch from such memory are read by the GPU's copy engine directly, without the staging copy.  Prefer this
-   for large arrays on a two-socket host: the runtime places the pages next to the GPU, whereas a buffer registered in
-   place (ecl_hip_pin_host) stays where its pages were first touched - from the far socket the copy runs at about half
-   the rate (30 against 57 GB/s measured: 0.93 instead of 1.3 G scalars/s for `mul`). */
+/* Page-locked host memory (hipHostMalloc / hipHostFree): scalar arrays given to ecl_hip_mul_batch from such memory are read by the
+   GPU's copy engine directly (57 GB/s), pageable ones go through a staging copy (18 GB/s: 0.57 instead of 1.3 G scalars/s for `mul`).
+   The runtime places the pages next to the GPU, which matters on a two-socket host: from the far socket the copy runs at about half
+   the rate (30 against 57 GB/s measured). */
 void *ecl_hip_alloc_host(size_t bytes);
 void ecl_hip_free_host(void *p);
 

@@ -522,10 +522,9 @@ def test_mul_batch_sizes_just_below_a_power_of_two(n):
 
 
 def test_pinning_small_and_large_scalar_arrays():
-    """ecl_hip_pin_host / mul_batch with page-locked scalars: large arrays go by DMA from the caller's memory, arrays
-    below 1 MiB are accepted but left unpinned (registering heap pages that small buffers share with other host data
-    ended in GPU memory faults a few calls later - the pattern below, found by tools/fuzz_mul_gpu.py).  Results are
-    the same either way."""
+    """ecl_hip_pin_host / ecl_hip_unpin_host are accepted and do nothing since round 5 (registering heap memory in place
+    ended in GPU memory faults inside the runtime: the pattern below found it in round 2 for small arrays, tools/repro_pin_fault.py
+    for large ones); mul_batch from such arrays is staged, from ecl_hip_alloc_host memory it is read by DMA.  Same records either way."""
     import ctypes as C
     from ecloop_amd import Device, capi
     rng = np.random.default_rng(3)
@@ -550,6 +549,13 @@ def test_pinning_small_and_large_scalar_arrays():
                 assert d.lib.ecl_hip_unpin_host(big.ctypes.data) == 0
                 assert np.array_equal(np.sort(out[: cnt.value], order=["key_offset", "compressed"]), ref)
         assert d.lib.ecl_hip_unpin_host(big.ctypes.data) == 0  # not pinned any more: a no-op, not an error
+        ptr = d.lib.ecl_hip_alloc_host(big.nbytes)  # page-locked by the runtime: the DMA path
+        assert ptr
+        pl = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=big.shape)
+        pl[:] = big
+        assert d.lib.ecl_hip_mul_batch(d.h, ptr, len(big), out.ctypes.data, len(out), C.byref(cnt)) == 0
+        assert np.array_equal(np.sort(out[: cnt.value], order=["key_offset", "compressed"]), ref)
+        d.lib.ecl_hip_free_host(ptr)
     finally:
         d.close()
 

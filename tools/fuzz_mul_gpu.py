@@ -47,6 +47,7 @@ def main():
         if mode == "ones" and n > (1 << 20):
             words = synth_bloom_words(nw, 7, "a|b")  # keep the record count of the big batches moderate
         pinned = rnd.random() < 0.5
+        host_ptr = None  # pinned: the scalars in page-locked memory from ecl_hip_alloc_host (read by DMA), else a pageable numpy array (staged)
         window = rnd.choice([0, 0, rnd.randrange(8, 25), rnd.randrange(8, 27)])
         raw = trials % 3 == 2
         if raw:  # the scalars ARE the SHA-256 digests of random lines
@@ -61,14 +62,22 @@ def main():
                 v = int.from_bytes(hashlib.sha256(blob[int(starts[i]): int(starts[i]) + int(lens[i])]).digest(), "big")
                 K[i] = [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
             text = np.frombuffer(blob, dtype=np.uint8)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)  # a run that dies (GPU fault) leaves the trial it was in
+        open(os.path.join(ROOT, "gpurun_out", "fuzz_mul_last_trial.txt"), "w").write("seed %d trial %d %r\n" % (
+            seed, trials, dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, window=window, raw=raw)))
         if os.environ.get("FUZZ_VERBOSE"):
             print("trial", trials, dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, window=window, raw=raw), flush=True)
         d = Device(0, a33=a33, a65=a65)
         try:
             d.set_bloom(words)
             d.set_mul_window(window)
-            if pinned:
-                assert d.lib.ecl_hip_pin_host(K.ctypes.data, K.nbytes) == 0
+            if pinned and not raw:
+                host_ptr = d.lib.ecl_hip_alloc_host(K.nbytes)
+                assert host_ptr
+                Kp = np.ctypeslib.as_array(C.cast(host_ptr, C.POINTER(C.c_uint64)), shape=K.shape)
+                Kp[:] = K
+                K = Kp
+            assert d.lib.ecl_hip_pin_host(K.ctypes.data, K.nbytes) == 0  # (accepted, does nothing since round 5)
             cap = 2 * n + 16
             out = np.zeros(cap, dtype=capi.FOUND_DTYPE)
             cnt = C.c_uint32()
@@ -76,8 +85,7 @@ def main():
                 rc = d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, int(lens.sum()), table.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
             else:
                 rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
-            if pinned:
-                d.lib.ecl_hip_unpin_host(K.ctypes.data)
+            d.lib.ecl_hip_unpin_host(K.ctypes.data)
             assert rc == 0, rc
             X, Y = np.zeros_like(K), np.zeros_like(K)
             ok = np.zeros(n, dtype=np.uint8)
@@ -86,6 +94,9 @@ def main():
             assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
             assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
         finally:
+            if host_ptr:
+                K = np.array(K)  # the checks below read the scalars after the page-locked copy is gone
+                d.lib.ecl_hip_free_host(host_ptr)
             d.close()
         want = set()
         for comp, hh, on in ((1, h33, a33), (0, h65, a65)):
