@@ -211,7 +211,7 @@ class Device:
         return out[: min(n.value, cap)], n.value
 
     def set_mul_window(self, bits):
-        """window width of this context's `mul` table (8..24; 0 = automatic: 20, then 22 after 2^30 scalars)"""
+        """window width of this context's `mul` table (8..29 bits; 0 = automatic: 22, then 26 after 2^30 scalars)"""
         self._chk(self.lib.ecl_hip_set_mul_window(self.h, bits))
 
     def sort_list(self, h160):

@@ -29,7 +29,8 @@ static int ensure_gtable(ecl_hip* h) {
 // out, sample slots of every row - first, last, the low digits, the seams between threads, and a fixed pseudo-random set -
 // are compared with the double-and-add kernel.
 #define MUL_W_MIN 8u
-#define MUL_W_MAX 26u
+#define MUL_W_MAX 29u                 /* 8 rows x 2^28 points + 2^24: 138 GB, 9 additions per scalar - on request only (ecl_hip_set_mul_window): +2 % on
+                                         2^24-scalar calls, +3.8 % on 2^26 over 26 bits (profiles/r05_mul_w29.txt), seconds to build */
 #define MUL_W_START 22u               /* 11 rows x 2^21 points (signed digits), 1.5 GB */
 #define MUL_W_LONG 26u                /* 9 rows x 2^25 points + 2^22, 19.6 GB: 10 additions per scalar instead of 12 */
 #define MUL_LONG_AFTER (1ull << 30)   /* scalars a context has seen before it moves to MUL_W_LONG: the wider table gains ~0.1 ns per scalar,

@@ -142,8 +142,8 @@ int ecl_hip_reserve(ecl_hip *h, uint64_t nkeys, uint32_t cap);
    HBM rather than for a CPU cache (the reference: 14 bits, 19.9 MB), with signed digits (a row holds 2^(W-1) points, a digit above
    2^(W-1) adds the negated point and carries): a context starts on 22 bits (12 rows, 11 * 2^21 + 2^14 points of 64 bytes = 1.5 GB,
    ~40 ms with the first call) and moves to 26 bits (10 rows, 19.6 GB, ~90 ms: 10 additions per scalar instead of 19) once it has
-   multiplied 2^30 scalars, which is when the wider table has paid for its build (any width 8...26 can be fixed with
-   ecl_hip_set_mul_window).  A table is checked against the double-and-add kernel
+   multiplied 2^30 scalars, which is when the wider table has paid for its build (any width 8...29 can be fixed with
+   ecl_hip_set_mul_window; 29 bits = 9 additions per scalar from a 138 GB table, for runs of 10^11 scalars and more).  A table is checked against the double-and-add kernel
    on sample slots before use (ECL_E_SELFTEST on a mismatch), shared between the contexts of a device in the process
    and freed with the last of them.  Results do not depend on the width. */
 int ecl_hip_mul_batch(ecl_hip *h, const uint64_t (*scalars)[4], uint32_t n, ecl_found *out, uint32_t cap,
@@ -162,7 +162,7 @@ int ecl_hip_mul_batch_raw(ecl_hip *h, const uint8_t *text, uint32_t text_bytes, 
    counterpart of ecl_hip_reserve for `mul`; the reference builds its table at the start of cmd_mul (main.c:543). */
 int ecl_hip_reserve_mul(ecl_hip *h, uint32_t n, uint32_t cap);
 
-/* Optional: fix the window width of this context's `mul` table (8..26 bits; 0 = automatic, the default) from the next
+/* Optional: fix the window width of this context's `mul` table (8..29 bits; 0 = automatic, the default) from the next
    ecl_hip_mul_batch on - a caller that knows it will multiply billions of scalars takes 22 at once.  No reference
    counterpart other than the compile-time _GTABLE_W (lib/ecc.c:876). */
 int ecl_hip_set_mul_window(ecl_hip *h, uint32_t bits);

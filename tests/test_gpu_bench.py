@@ -55,6 +55,8 @@ def test_bench_secondary_legs_at_reduced_size():
     assert c3["windows"] == 1 and c3["config"]["checked"] == 1 << 32 and c3["config"]["found_list_matches_oracle_on_sample"] and c3["value"] > 3000
     assert 0 < c3["config"]["setup_share"] < 0.05
     assert api["config"]["found_list_matches_oracle_on_sample"] and api["config"]["window_bits"] == 26 and api["value"] > 100
+    wide = api["widest_table"]  # the same call on the 29-bit table (138 GB): same records, its own rate
+    assert wide["window_bits"] == 29 and wide.get("records_equal_to_the_26_bit_run") and wide["value"] > 100, wide
     assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
     assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
     for leg in (c2, api):  # rooflines priced with the kernels' own PMC profiles when those are in the tree
