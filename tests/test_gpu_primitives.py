@@ -147,7 +147,7 @@ def test_c_abi_error_codes():
             assert lib.ecl_hip_strerror(rc)
         # round-3 entry points
         bits = C.c_uint32(9)
-        assert lib.ecl_hip_set_mul_window(h, 7) == -1 and lib.ecl_hip_set_mul_window(h, 27) == -1 and lib.ecl_hip_set_mul_window(None, 18) == -1
+        assert lib.ecl_hip_set_mul_window(h, 7) == -1 and lib.ecl_hip_set_mul_window(h, 30) == -1 and lib.ecl_hip_set_mul_window(None, 18) == -1
         assert lib.ecl_hip_get_mul_window(h, C.byref(bits)) == 0 and bits.value == 0 and lib.ecl_hip_get_mul_window(h, None) == -1
         assert lib.ecl_hip_reserve_mul(h, 0, 16) == -1 and lib.ecl_hip_reserve_mul(None, 16, 16) == -1
         text = np.frombuffer(b"abcdef", dtype=np.uint8)
