@@ -28,7 +28,7 @@ EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
     "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
-    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window", "ecl_hip_fetch_found",
+    "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window", "ecl_hip_fetch_found", "ecl_hip_plan_geometry",
 ]
 
 _lib = None
@@ -62,6 +62,7 @@ def load():
     lib.ecl_hip_bloom_insert_count.argtypes = [P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ecl_hip_set_geometry.argtypes = [P, C.c_uint32, C.c_uint32]
     lib.ecl_hip_get_geometry.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.ecl_hip_plan_geometry.argtypes = [P, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ecl_hip_get_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_reset_timing.argtypes = [P]
     lib.ecl_hip_get_setup_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -169,6 +170,12 @@ class Device:
         b, t = C.c_uint32(), C.c_uint32()
         self._chk(self.lib.ecl_hip_get_geometry(self.h, C.byref(b), C.byref(t)))
         return b.value, t.value
+
+    def plan_geometry(self, nkeys):
+        """-> (half_group, lanes, groups per lane) that add_range would use for a call of nkeys keys"""
+        b, t, nb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.ecl_hip_plan_geometry(self.h, nkeys, C.byref(b), C.byref(t), C.byref(nb)))
+        return b.value, t.value, nb.value
 
     def add_range(self, start, nkeys, cap=4096):
         """-> (records as numpy structured array, total hit count). Raises on overflow unless total <= cap."""

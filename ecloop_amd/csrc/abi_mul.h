@@ -13,14 +13,14 @@ static int ensure_gtable(ecl_hip* h) {
       cur = sc_add(cur, base);
     }
   }
-  u32* d_k = nullptr;
-  HIPCHK(h, hipMalloc(&d_k, ks.size() * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&h->d_gtab, slots * 16 * sizeof(u32)));
-  HIPCHK(h, hipMemcpy(d_k, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_mul_g, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, h->stream, d_k, h->d_gtab, (u8*)nullptr, (u32)slots);
+  dbuf<u32> d_k, tab;  // freed on every way out; the table is handed to the context only when it is complete
+  HIPCHK(h, hipMalloc(&d_k.p, ks.size() * sizeof(u32)));
+  HIPCHK(h, hipMalloc(&tab.p, slots * 16 * sizeof(u32)));
+  HIPCHK(h, hipMemcpy(d_k.p, ks.data(), ks.size() * sizeof(u32), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_mul_g, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, h->stream, d_k.p, tab.p, (u8*)nullptr, (u32)slots);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipFree(d_k));
+  h->d_gtab = tab.p, tab.p = nullptr;
   return ECL_OK;
 }
 

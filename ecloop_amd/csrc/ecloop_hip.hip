@@ -509,6 +509,20 @@ static bool nkeys_ok(const ecl_hip* h, u64 nkeys) {
   const u64 ngroups = (nkeys + 2ull * B - 1) / (2ull * B);
   return (ngroups + h->Tmax - 1) / h->Tmax < (1ull << 32);
 }
+extern "C" int ecl_hip_plan_geometry(ecl_hip* h, uint64_t nkeys, uint32_t* half_group, uint32_t* lanes, uint32_t* groups_per_lane) {
+  if (!h || nkeys == 0) return ECL_E_ARG;
+  HIPCHK(h, hipSetDevice(h->dev));
+  int rc = default_lanes(h);
+  if (rc != ECL_OK) return rc;
+  if (!nkeys_ok(h, nkeys)) return ECL_E_ARG;
+  u32 B, nb, T;
+  call_geometry(h, nkeys, B, nb, T);
+  if (half_group) *half_group = B;
+  if (lanes) *lanes = T;
+  if (groups_per_lane) *groups_per_lane = nb;
+  return ECL_OK;
+}
+
 // device buffers of a call with that geometry: lane centres and prefix-product chains
 static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
   if (h->cxy_T < T) {

@@ -186,6 +186,12 @@ int ecl_hip_set_geometry(ecl_hip *h, uint32_t half_group, uint32_t max_lanes);
    lane equally busy (no tail) and can be continued by the next contiguous call without re-initialisation. */
 int ecl_hip_get_geometry(ecl_hip *h, uint32_t *half_group, uint32_t *lanes);
 
+/* The geometry ecl_hip_add_range would walk a call of `nkeys` keys with: half group, lanes, groups per lane.  While the half group is
+   left automatic it follows a measured cost model (one inversion per lane and group against keeping the chip oversubscribed):
+   8 x 2^17 lanes for the reference's 2^21-key job, 32 x 2^18 for 2^24 keys, 128 x 2^21 for 2^29, 1024 x 2^21 for 2^32.  Contiguous
+   calls continue the resident walk only while this stays the same, i.e. for calls of one size. */
+int ecl_hip_plan_geometry(ecl_hip *h, uint64_t nkeys, uint32_t *half_group, uint32_t *lanes, uint32_t *groups_per_lane);
+
 /* Measurement: accumulated HIP-event time of the main add kernel since the last reset, and launch count. */
 int ecl_hip_get_timing(ecl_hip *h, double *kernel_ms, uint64_t *launches, uint64_t *keys);
 int ecl_hip_reset_timing(ecl_hip *h);

@@ -123,6 +123,24 @@ def test_sparse_bloom_false_positives_and_continuation():
     assert len(lines) == g["count"] and orc.digest(lines) == g["sha256_sorted"]
 
 
+def test_planned_geometry_follows_the_cost_model():
+    """ecl_hip_plan_geometry: the half group of a call by its size (ecloop_hip.hip: auto_half_group, fitted to profiles/r05_short_calls.txt
+    and r04_short_calls.txt), lanes a multiple of 256 that cover the range with equal work, and a caller-set geometry taken as it is"""
+    from ecloop_amd import Device
+    d = Device(0)
+    try:
+        want = {11: 8, 16: 8, 21: 8, 22: 16, 23: 32, 24: 32, 25: 32, 26: 64, 27: 64, 28: 64, 29: 128, 30: 256, 31: 512, 32: 1024, 36: 1024}
+        for lg, b in want.items():
+            hb, lanes, nb = d.plan_geometry(1 << lg)
+            assert hb == b and lanes % 256 == 0 and lanes * nb * 2 * hb >= 1 << lg, (lg, hb, lanes, nb)
+            assert lanes == min(max((1 << lg) // (2 * hb), 256), 1 << 21) and (nb == 1 or lg > 32), (lg, hb, lanes, nb)
+        assert d.plan_geometry((1 << 21) + 5)[0] == 8 and d.plan_geometry(3 << 22)[0] in (16, 32)
+        d.set_geometry(64, 4096)
+        assert d.plan_geometry(1 << 21) == (64, 4096, 4) and d.plan_geometry(1 << 32)[:2] == (64, 4096)
+    finally:
+        d.close()
+
+
 def test_automatic_geometry_of_short_calls():
     """no geometry set: the library picks the half group by its cost model (ecloop_hip.hip: auto_half_group - 8 for the reference's 2^21-key
     job, 16 / 32 for 2^22 ... 2^25, up to 1024 for 2^32).  The reference's golden false-positive set over two 2^21-key jobs as two
