@@ -38,6 +38,8 @@ struct ecl_hip {
   u32* d_aux = nullptr;                        // [0]=C0, [1]=jump, [2..33]=ladder : 34 points x 16 words
   u32* d_auxk = nullptr;                       // scalars for the above
   uint4* d_cxy = nullptr; size_t cxy_T = 0;
+  uint4* d_ctab = nullptr; size_t ctab_cap = 0;  // (g + 1) * D, g < T, for the geometry of d_aux (k_init_centres_table)
+  bool ctab_valid = false;
   uint4* d_scr = nullptr; u32* d_scr2 = nullptr; size_t scr_elems = 0;  // prefix-product chains
   u64* d_bloom = nullptr; u64 bloom_words = 0;
   // `mul`: scalars travel in pieces through MUL_NBUF device buffers (and as many pinned staging buffers for pageable callers), the copy
@@ -154,7 +156,7 @@ void ecl_hip_close(ecl_hip* h) {
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-  (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy);
+  (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy), (void)hipFree(h->d_ctab);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
   for (int i = 0; i < MUL_NBUF; ++i) {
     (void)hipFree(h->d_kbuf[i]);
@@ -532,6 +534,13 @@ static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
     HIPCHK(h, hipMalloc(&h->d_cxy, (size_t)T * 4 * sizeof(uint4)));
     h->cxy_T = T;
   }
+  if (h->ctab_cap < T) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_ctab) HIPCHK(h, hipFree(h->d_ctab));
+    h->d_ctab = nullptr, h->ctab_cap = 0, h->ctab_valid = false, h->aux_B = h->aux_T = 0;
+    HIPCHK(h, hipMalloc(&h->d_ctab, (size_t)T * 4 * sizeof(uint4)));
+    h->ctab_cap = T;
+  }
   const size_t need = (size_t)T * B * 2;
   if (h->scr_elems < need) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -616,16 +625,31 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
       hipLaunchKernelGGL(k_mul_g, dim3(1), dim3(64), 0, h->stream, h->d_auxk, h->d_aux + 16, (u8*)nullptr, 33u);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(h->jump_host, h->d_aux + 16, 16 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+      // ... and so do the multiples (g + 1) * D, g < T (D = 2B * 2^offs * G = the first ladder point): the lane centres C_0 = D, D = D
+      if (B >= 8)
+        hipLaunchKernelGGL(k_init_centres_batched, dim3((T / INIT_R + 255) / 256), dim3(256), 0, h->stream, h->d_aux + 32, h->d_aux + 32,
+                           h->d_ctab, T, (u32*)h->d_scr);
+      else
+        hipLaunchKernelGGL(k_init_centres, dim3(T / 256), dim3(256), 0, h->stream, h->d_aux + 32, h->d_aux + 32, h->d_ctab, T);
+      HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipStreamSynchronize(h->stream));
-      h->aux_B = B, h->aux_T = T;
+      h->aux_B = B, h->aux_T = T, h->ctab_valid = true;
     }
     // C0 = (k0 + B*s)*G through the window table (19 additions, ~0.1 ms), the scalar travelling as a kernel argument;
     // then the lane centres C0 + g*D.  Nothing here waits for the host: the search kernel queues right behind.
+    // (round 5) ... or, unless E = C0 - D is the point at infinity, E through the window table and the centres E + (g + 1) D from the cached
+    // multiples of D: one affine addition per lane (k_init_centres_table)
+    const u256 c0s = sc_add(k0, sc_mul_u64(s, B)), es = sc_add(c0s, sc_neg(sc_mul_u64(s, group)));
+    const bool from_table = h->ctab_valid && (es.w[0] | es.w[1] | es.w[2] | es.w[3]) != 0;
     scalar_arg c0;
-    words_of(c0.w, sc_add(k0, sc_mul_u64(s, B)));
+    words_of(c0.w, from_table ? es : c0s);
     hipLaunchKernelGGL(k_mul_window_one, dim3(1), dim3(64), 0, h->stream, c0, h->d_gtab, h->d_aux);
     HIPCHK(h, hipGetLastError());
-    if (B >= 8)  // the chain scratch (T * B * 36 bytes) holds the 144 bytes per lane the batched set-up parks
+    if (from_table && T >= (1u << 19))
+      hipLaunchKernelGGL(k_init_centres_table<8u>, dim3((T / 8u + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_ctab, h->d_cxy, T);
+    else if (from_table)
+      hipLaunchKernelGGL(k_init_centres_table<4u>, dim3((T / 4u + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_ctab, h->d_cxy, T);
+    else if (B >= 8)  // the chain scratch (T * B * 36 bytes) holds the 144 bytes per lane the batched set-up parks
       hipLaunchKernelGGL(k_init_centres_batched, dim3((T / INIT_R + 255) / 256), dim3(256), 0, h->stream, h->d_aux, h->d_aux + 32,
                          h->d_cxy, T, (u32*)h->d_scr);
     else

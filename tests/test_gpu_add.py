@@ -103,6 +103,50 @@ def test_centre_equals_jump_point_doubling_path():
     assert len(lines) == nkeys
 
 
+def test_lane_centres_from_the_table_of_multiples_and_its_exceptions():
+    """a non-contiguous call positions its lanes as E + (g + 1) D from the cached multiples of D = 2B G, E = C0 - D (k_init_centres_table).
+    With half group 8 (D = 16 G): start = 16 g + 24 makes E equal to the table point of lane g (same x: that lane takes the complete formulas,
+    here a doubling), start = 8 makes E the point at infinity (the call falls back to the ladder kernel); then a larger geometry, a second call
+    on the same context (table cached), a strided context, and the automatic geometry from far-apart starts.  Every key against the oracle."""
+    from ecloop_amd import Device
+    B, T = 8, 256
+    nkeys = 2 * B * T
+    for start in (16 * 5 + 24, 16 * 255 + 24, 24, 8, 9, 1000003):
+        lines = lines_of(dev_dump(start, nkeys, geometry=(B, T)), start)
+        assert len(lines) == nkeys
+        assert sorted(int(l.split("\t")[2], 16) for l in lines) == list(range(start, start + nkeys))
+        for l in lines:
+            k = int(l.split("\t")[2], 16)
+            x, y = orc.point_of(k)
+            assert start <= k < start + nkeys and l.split("\t")[1] == orc.hex160(orc.hash160(x, y, True)), (start, hex(k))
+    flt = orc.OrcFilter(bloom_words=ONES)
+    d = Device(0)
+    try:
+        d.set_bloom(ONES)
+        d.set_geometry(64, 512)
+        for start in (0x9000, 0x51234567, 0x9000, (1 << 200) + 77):  # non-contiguous: each call re-positions from the cached table
+            recs, n = d.add_range(start, 2048 * 4, cap=2048 * 4)
+            rc, out, cnt, _, hashed = orc.add_range(flt, start, start + 2048 * 4, verify=False, threads=4, cap=1 << 14)
+            assert n == cnt == hashed and sorted(lines_of(recs, start)) == sorted(orc.found_lines(out, cnt)), hex(start)
+        assert d.setup_timing()[1] == 4
+    finally:
+        d.close()
+    d = Device(0, ord_offs=13)  # stride 2^13: D = 2B * 2^13 G
+    try:
+        d.set_bloom(ONES)
+        d.set_geometry(16, 256)
+        for start in (0x777777, (1 << 150) + 5):
+            recs, n = d.add_range(start, 2048 * 2, cap=4096)
+            want = []
+            for g in range(2):  # the oracle dumps one 2048-key group of a strided scan per one-key range (main.c:442)
+                s0 = (start + g * 2048 * (1 << 13)) % orc.N
+                rc, out, cnt, _, _ = orc.add_range(flt, s0, s0 + 1, offs=13, verify=False, cap=4096)
+                want += orc.found_lines(out, cnt)
+            assert n == 4096 and sorted(lines_of(recs, start, 13)) == sorted(want)
+    finally:
+        d.close()
+
+
 def test_sparse_bloom_false_positives_and_continuation():
     """SURVEY §8c F9: same false-positive list as the reference over two reference jobs (2^22 keys);
     done as two contiguous calls so the second one continues from the walk state left in HBM."""
