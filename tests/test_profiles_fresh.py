@@ -66,3 +66,33 @@ def test_profile_is_self_consistent():
     assert abs(c["fetch_stream16_reported_over_actual"] - 0.5) < 0.02 and abs(c["write_stream16_reported_over_actual"] - 1.0) < 0.02
     assert 56 < c["fetch_reported_bytes_per_random8_rd_5900MB"] < 70  # one 64-byte request per random 8-byte probe
     assert abs(t["bytes_per_key_corrected"] - (t["chain_bytes_per_key_each_way"] + t["probe_fetch_bytes_per_key_reported"] + t["write_bytes_per_key_corrected"])) < 1e-6
+
+
+def test_static_mix_of_the_mul_kernel_matches_its_profile():
+    """the same for k_mul_check and profiles/rNN_roofline_mul.json (bench.py prices `secondary.cfg4.api.roofline` and its `mix_ceiling` with
+    it): the kernel's fingerprint (tools/isa_mix.py: analyse_mul) against the one stored with the counters; structural: the window loop is
+    free of scratch traffic and holds the 918 multiply-adds of one XYZZ addition (8 M + 2 S), and the static per-scalar estimate agrees with
+    the PMC count of the profiled build"""
+    from ecloop_amd.build import ASM, build_library
+    import isa_mix
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        build_library()
+    if not os.path.exists(ASM):
+        pytest.skip("no hipcc and no kept assembly: nothing to analyse")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_roofline_mul.json")))
+    assert files, "no profiles/rNN_roofline_mul.json: run tools/collect_profiles.sh on the GPU box"
+    prof, name = json.load(open(files[-1])), os.path.basename(files[-1])
+    m = isa_mix.analyse_mul(ASM)
+    fp = m["fingerprint"]
+    assert fp["window_loop_scratch"] == 0 and 880 <= fp["window_loop_mad64"] <= 960 and fp["walk_back_loop_valu"] > 6000, fp
+    want = (prof.get("static_mix") or {}).get("fingerprint")
+    if not want:
+        pytest.skip(f"{name} predates the stored class mix")
+    stale = [f"{k}: built {fp.get(k)} vs {v}" for k, v in want.items() if k in fp and abs(fp[k] - v) > max(0.01 * v, 1)]
+    if stale:
+        msg = f"{name} was collected on another build of k_mul_check ({'; '.join(stale)}): re-run tools/collect_profiles.sh"
+        assert os.environ.get("ECL_REQUIRE_FRESH_PROFILES") != "1", msg
+        warnings.warn(msg)
+    else:
+        est, pmc = m["per_scalar_static"]["valu"], prof["derived"]["valu_lane_ops_per_scalar"]
+        assert 0.90 < est / pmc < 1.05, (est, pmc)  # the static estimate leaves the inversion's share out and counts rarely taken ring blocks
