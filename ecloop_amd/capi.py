@@ -112,6 +112,7 @@ class Device:
     def __init__(self, device=0, a33=True, a65=False, endo=False, ord_offs=0):
         self.lib = load()
         self.h = C.c_void_p()
+        self.a33, self.a65, self.endo = bool(a33), bool(a65), bool(endo)
         flags = (ADDR33 if a33 else 0) | (ADDR65 if a65 else 0) | (ENDO if endo else 0)
         rc = self.lib.ecl_hip_open(C.byref(self.h), device, flags, ord_offs)
         if rc != 0:

@@ -830,3 +830,63 @@ int orc_mul_batch(int check33, int check65, const orc_filter *flt, const orc_fe 
   if (nout) *nout = cnt;
   return err;
 }
+
+/* ---------------------------------------------------------------- cmd mul at scale: what every input line's hash160 must be
+   main.c:486-540 as a table: jobs of 2048 scalars (MAX_LINE_SIZE / GROUP, main.c:556-566), each one ec_gtable_mul per scalar
+   (ecc.c:907-929) + ONE ec_jacobi_grprdc per job (ecc.c:695-707) + addr33 / addr65 (addr.c:99-131); worker threads pull jobs from a
+   counter as cmd_mul_worker does from its queue (main.c:486-501).  A scalar that is 0 (mod n) has no point (z = 0; the reference lets it
+   poison its job): ok[i] = 0, its slot is left out of the job's shared inversion, its hashes are zeroed. */
+typedef struct mul_many_state {
+  const orc_fe *pk;
+  u64 n, next;
+  u32 *h33, *h65;
+  u8 *ok;
+  pthread_mutex_t lock;
+} mul_many_state;
+
+static void *mul_many_worker(void *arg) {
+  mul_many_state *st = (mul_many_state *)arg;
+  orc_pt *cp = (orc_pt *)malloc(GROUP * sizeof(orc_pt));
+  u8 *inf = (u8 *)malloc(GROUP);
+  for (;;) {
+    pthread_mutex_lock(&st->lock);
+    u64 at = st->next;
+    st->next += GROUP;
+    pthread_mutex_unlock(&st->lock);
+    if (at >= st->n) break;
+    u64 cnt = st->n - at < GROUP ? st->n - at : GROUP;
+    for (u64 i = 0; i < cnt; ++i) {
+      orc_gtable_mul(&cp[i], st->pk[at + i]);
+      inf[i] = !(cp[i].z[0] | cp[i].z[1] | cp[i].z[2] | cp[i].z[3]);
+      if (inf[i]) fe_set(cp[i].z, 1); /* keep it out of the shared inversion */
+    }
+    orc_pt_grprdc(cp, cnt);
+    for (u64 i = 0; i < cnt; ++i) {
+      if (st->ok) st->ok[at + i] = !inf[i];
+      if (st->h33) {
+        if (inf[i]) memset(st->h33 + 5 * (at + i), 0, 20);
+        else orc_hash160_33(st->h33 + 5 * (at + i), cp[i].x, cp[i].y);
+      }
+      if (st->h65) {
+        if (inf[i]) memset(st->h65 + 5 * (at + i), 0, 20);
+        else orc_hash160_65(st->h65 + 5 * (at + i), cp[i].x, cp[i].y);
+      }
+    }
+  }
+  free(cp), free(inf);
+  return NULL;
+}
+
+void orc_mul_hash160_many(const orc_fe *pk, uint64_t n, uint32_t *h33, uint32_t *h65, uint8_t *ok, int threads) {
+  orc_gtable_init();
+  mul_many_state st;
+  memset(&st, 0, sizeof st);
+  st.pk = pk, st.n = n, st.h33 = h33, st.h65 = h65, st.ok = ok;
+  pthread_mutex_init(&st.lock, NULL);
+  int nt = threads < 1 ? 1 : threads;
+  pthread_t *th = (pthread_t *)malloc(nt * sizeof(pthread_t));
+  for (int i = 0; i < nt; ++i) pthread_create(&th[i], NULL, mul_many_worker, &st);
+  for (int i = 0; i < nt; ++i) pthread_join(th[i], NULL);
+  free(th);
+  pthread_mutex_destroy(&st.lock);
+}

@@ -107,6 +107,11 @@ int orc_add_range(const orc_add_cfg *cfg, const orc_filter *flt, const orc_fe ra
 int orc_mul_batch(int check33, int check65, const orc_filter *flt, const orc_fe *pk, uint64_t n, orc_found *out,
                   uint64_t cap, uint64_t *nout);
 
+/* cmd_mul at scale: hash160 of k[i]*G for every scalar, in input order, the way the reference's workers get them (2048-scalar jobs:
+   ec_gtable_mul each, one ec_jacobi_grprdc per job, addr33/addr65; main.c:486-540).  h33 / h65: n x 5 words or NULL; ok[i] = 0 for a
+   scalar that is 0 (mod n) (no point; hashes zeroed).  `threads` workers pull jobs from one counter. */
+void orc_mul_hash160_many(const orc_fe *pk, uint64_t n, uint32_t *h33, uint32_t *h65, uint8_t *ok, int threads);
+
 /* calc_priv (main.c:267-276) */
 void orc_calc_priv(orc_fe pk, const orc_fe start, const orc_fe stride, uint64_t off, uint8_t endo);
 

@@ -152,6 +152,21 @@ def mul_batch(flt, scalars, a33=True, a65=False, cap=1 << 16):
     return rc, out, nout.value
 
 
+def mul_hash160_many(K, a33=True, a65=False, threads=None):
+    """hash160 of every scalar of K ((n, 4) uint64, little-endian limbs) the way cmd_mul's workers compute them (2048-scalar jobs:
+    ec_gtable_mul, one grprdc, addr33 / addr65) -> (h33 or None, h65 or None, ok): (n, 5) uint32 each, ok[i] = 0 for k = 0 (mod n)"""
+    K = np.ascontiguousarray(K, dtype=np.uint64)
+    n = len(K)
+    h33 = np.zeros((n, 5), np.uint32) if a33 else None
+    h65 = np.zeros((n, 5), np.uint32) if a65 else None
+    ok = np.zeros(n, np.uint8)
+    if threads is None:
+        threads = max(1, min(len(os.sched_getaffinity(0)), 128))
+    lib().orc_mul_hash160_many(C.c_void_p(K.ctypes.data), C.c_uint64(n), C.c_void_p(h33.ctypes.data if a33 else None),
+                               C.c_void_p(h65.ctypes.data if a65 else None), C.c_void_p(ok.ctypes.data), C.c_int(threads))
+    return h33, h65, ok
+
+
 def sn_from_hex(s):
     r = FE()
     lib().orc_sn_from_hex(r, s.encode())

@@ -349,15 +349,20 @@ def test_device_side_list_confirm():
         d.close()
 
 
-def test_mult_verify_gtable_against_double_and_add():
-    """the reference's hidden `mult-verify` (lib/bench.c:143-166): fixed-base window multiplication == double-and-add
-    for k = 2..16001, here through the hashes of both kernels; plus scalars that exercise every window, >= n, and 0."""
+def test_mult_verify_gtable_against_the_oracle():
+    """the reference's hidden `mult-verify` (lib/bench.c:143-166: fixed-base window multiplication == double-and-add for
+    k = 2..16001), with the ORACLE as the yardstick of both device paths: ecl_hip_mul_batch's hash160s (window table, one inversion per
+    thread) and the double-and-add kernel's must equal orc.mul_hash160_many's (ec_gtable_mul + grprdc + addr33/addr65 restated,
+    lib/ecc.c:907-929, main.c:458-479) for every scalar; plus scalars that exercise every window, >= n, and 0."""
     from ecloop_amd import Device
     ks = list(range(2, 16002))
     rng = np.random.default_rng(11)
     ks += [int.from_bytes(rng.bytes(32), "big") for _ in range(4096)]            # any 256-bit value, some >= n
     ks += [orc.N - 1, orc.N + 1, orc.N + 12345, (1 << 256) - 1, 1 << 255, (1 << 14) - 1, 1 << 14, 1 << 252]
     ks += [sum(((1 << 14) - 1) << (14 * w) for w in range(0, 19, 2)) % (1 << 256)]
+    K = np.array([[(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for v in ks], dtype=np.uint64)
+    w33, w65, wok = orc.mul_hash160_many(K, True, True)
+    assert wok.all()
     d = Device(0, a33=True, a65=True)
     try:
         d.set_bloom(ONES)
@@ -366,25 +371,23 @@ def test_mult_verify_gtable_against_double_and_add():
         xs, ys, ok = d.diag_mulg([k % orc.N for k in ks])
         h33, h65 = d.diag_hash160(xs, ys)
         assert all(ok)
-        got33 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if r["compressed"]}
-        got65 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if not r["compressed"]}
-        assert len(got33) == len(got65) == len(ks)
-        for i in range(len(ks)):
-            assert got33[i] == tuple(h33[i]) and got65[i] == tuple(h65[i]), hex(ks[i])
-        # and against the oracle for a few (the double-and-add kernel itself is pinned elsewhere)
-        for i in (0, 1, 15999, len(ks) - 1, len(ks) - 5):
-            x, y = orc.point_of(ks[i] % orc.N)
-            assert tuple(orc.hash160(x, y, True)) == got33[i]
     finally:
         d.close()
+    got33 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if r["compressed"]}
+    got65 = {int(r["key_offset"]): tuple(r["h160"]) for r in recs if not r["compressed"]}
+    assert len(got33) == len(got65) == len(ks)
+    for i in range(len(ks)):
+        assert got33[i] == tuple(w33[i]) and got65[i] == tuple(w65[i]), hex(ks[i])
+    assert np.array_equal(np.array(h33, dtype=np.uint32), w33) and np.array_equal(np.array(h65, dtype=np.uint32), w65)  # the double-and-add kernel too
 
 
-@pytest.mark.parametrize("n", [(1 << 18) + 77, (1 << 20) + 4099, (1 << 22) + (1 << 19) + 5, (1 << 23) + 12345])
-def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
+@pytest.mark.parametrize("n,W", [((1 << 18) + 77, 0), ((1 << 20) + 4099, 26), ((1 << 22) + (1 << 19) + 5, 0), ((1 << 23) + 12345, 26)])
+def test_mul_batched_inversion_every_scalar_against_the_oracle(n, W):
     """ecl_hip_mul_batch at sizes whose pieces (2^18, 2^19, ... 2^22 scalars, then the rest) give a thread 2, 4, 8, 16 and - the
-    largest size - 32 scalars (one shared inversion per thread, lib/ecc.c:695-707), over several staged pieces: with the all-ones filter every scalar comes back once, and every
-    hash160 must equal the one the double-and-add kernel + hash kernel give for the same scalar; scalars that are
-    0 (mod n) inside a batch are skipped without disturbing their neighbours' shared inversion."""
+    largest size - 32 scalars (one shared inversion per thread, lib/ecc.c:695-707), over several staged pieces, on the automatic
+    (22-bit) and the 26-bit table: with the all-ones filter every scalar comes back once, and every hash160 must equal the ORACLE's for
+    the same scalar (orc.mul_hash160_many: cmd_mul's 2048-scalar jobs restated, main.c:458-540); scalars that are 0 (mod n) inside a
+    batch are skipped without disturbing their neighbours' shared inversion."""
     import ctypes as C
     from ecloop_amd import Device, capi
     rng = np.random.default_rng(n)
@@ -397,49 +400,42 @@ def test_mul_batched_inversion_every_scalar_against_double_and_add(n):
     d = Device(0)
     try:
         d.set_bloom(ONES)
+        d.set_mul_window(W)
         out = np.zeros(n, dtype=capi.FOUND_DTYPE)
         cnt = C.c_uint32()
         rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt))
-        assert rc == 0 and cnt.value == n - len(zero_at)
-        X, Y = np.zeros_like(K), np.zeros_like(K)
-        ok = np.zeros(n, dtype=np.uint8)
-        h33 = np.zeros((n, 5), dtype=np.uint32)
-        h65 = np.zeros((n, 5), dtype=np.uint32)
-        assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
-        assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
+        assert rc == 0 and cnt.value == n - len(zero_at) and d.mul_window() == (W or 22)
     finally:
         d.close()
+    h33, _, ok = orc.mul_hash160_many(K, True, False)
     recs = out[: cnt.value]
     order = np.argsort(recs["key_offset"])
     offs = recs["key_offset"][order]
     want = np.setdiff1d(np.arange(n, dtype=np.uint64), np.array(zero_at, dtype=np.uint64))
-    assert np.array_equal(offs, want) and list(ok[zero_at]) == [0] * len(zero_at) and recs["compressed"].all()
+    assert np.array_equal(offs, want) and list(ok[zero_at]) == [0] * len(zero_at) and ok.sum() == n - len(zero_at) and recs["compressed"].all()
     assert np.array_equal(recs["h160"][order], h33[want.astype(np.int64)])
-    for i in (0, 1, n // 2):  # and the reference path itself against the oracle
-        k = sum(int(K[i][j]) << (64 * j) for j in range(4)) % orc.N
-        assert list(h33[i]) == orc.hash160(*orc.point_of(k), True)
 
 
-def _mul_all_against_double_and_add(d, K):
-    """every scalar of K through ecl_hip_mul_batch (all-ones filter) == double-and-add kernel + hash kernel; -> hits"""
+def _mul_all_against_the_oracle(d, K):
+    """every scalar of K through ecl_hip_mul_batch (all-ones filter) == the oracle's hash160 of that scalar (orc.mul_hash160_many:
+    ec_gtable_mul + one grprdc per 2048-scalar job + addr33/addr65, lib/ecc.c:907-929, main.c:458-479); -> hits.
+    A context that checks both address forms is compared on both."""
     import ctypes as C
     from ecloop_amd import capi
     n = len(K)
-    out = np.zeros(n, dtype=capi.FOUND_DTYPE)
+    both = bool(getattr(d, "a65", False))
+    out = np.zeros((2 if both else 1) * n, dtype=capi.FOUND_DTYPE)
     cnt = C.c_uint32()
-    assert d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt)) == 0
-    X, Y = np.zeros_like(K), np.zeros_like(K)
-    ok = np.zeros(n, dtype=np.uint8)
-    h33 = np.zeros((n, 5), dtype=np.uint32)
-    h65 = np.zeros((n, 5), dtype=np.uint32)
-    assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
-    assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
-    recs = out[: cnt.value]
-    order = np.argsort(recs["key_offset"])
+    assert d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, len(out), C.byref(cnt)) == 0
+    h33, h65, ok = orc.mul_hash160_many(K, True, both)
     want = np.nonzero(ok)[0]
-    assert np.array_equal(recs["key_offset"][order], want.astype(np.uint64))
-    assert np.array_equal(recs["h160"][order], h33[want])
-    return cnt.value
+    recs = out[: cnt.value]
+    for comp, hh in ((1, h33), (0, h65)) if both else ((1, h33),):
+        part = recs[recs["compressed"] == comp]
+        order = np.argsort(part["key_offset"])
+        assert np.array_equal(part["key_offset"][order], want.astype(np.uint64))
+        assert np.array_equal(part["h160"][order], hh[want])
+    return cnt.value // (2 if both else 1)
 
 
 def _digit_edge_scalars(rng, n, W):
@@ -465,7 +461,7 @@ def _digit_edge_scalars(rng, n, W):
 
 
 @pytest.mark.parametrize("W", [8, 13, 14, 16, 18, 20, 22, 24, 26, 27, 29])
-def test_mul_every_window_width_against_double_and_add(W):
+def test_mul_every_window_width_against_the_oracle(W):
     """the window width of `mul`'s table is a run-time choice (ecl_hip_set_mul_window; the reference's is the compile-time
     _GTABLE_W = 14, lib/ecc.c:876): results must not depend on it.  Widths that divide 256 and widths that leave a
     narrower last window, the table built by k_gtable_rows in one launch (small widths) and row group by row group."""
@@ -476,7 +472,7 @@ def test_mul_every_window_width_against_double_and_add(W):
     try:
         d.set_bloom(ONES)
         d.set_mul_window(W)
-        assert _mul_all_against_double_and_add(d, K) == n and d.mul_window() == W
+        assert _mul_all_against_the_oracle(d, K) == n and d.mul_window() == W
         with pytest.raises(Exception):
             d.set_mul_window(30)
         with pytest.raises(Exception):
@@ -491,7 +487,7 @@ def test_mul_short_scalars_cut_the_window_loop(W):
     the complete sum one by one).  The bound comes from the scalars' bit lengths, and the signed recoding can carry one window further
     than the bits reach, so: whole waves of scalars of every bit length 1..256 (thread t of a short batch owns scalar t, a wave = 64
     consecutive ones), the values around every 2^(jW-1) (where the carry into window j starts) and 2^(jW), waves that mix one long
-    scalar among short ones, consecutive keys from a puzzle range, and 0.  Every scalar against the double-and-add kernel."""
+    scalar among short ones, consecutive keys from a puzzle range, and 0.  Every scalar against the oracle."""
     from ecloop_amd import Device
     rng = np.random.default_rng(1000 + W)
     ks = []
@@ -516,10 +512,10 @@ def test_mul_short_scalars_cut_the_window_loop(W):
     try:
         d.set_bloom(ONES)
         d.set_mul_window(W)
-        assert _mul_all_against_double_and_add(d, K) == len(ks) - 64  # the 64 zeros have no point
+        assert _mul_all_against_the_oracle(d, K) == len(ks) - 64  # the 64 zeros have no point
         # ... and as a long batch, where a thread owns several scalars (scalar i = r * threads + t)
         big = np.concatenate([K] * ((1 << 18) // len(K) + 1))
-        assert _mul_all_against_double_and_add(d, big) == len(big) - 64 * ((1 << 18) // len(K) + 1)
+        assert _mul_all_against_the_oracle(d, big) == len(big) - 64 * ((1 << 18) // len(K) + 1)
     finally:
         d.close()
 
@@ -558,29 +554,31 @@ def test_mul_batch_sizes_just_below_a_power_of_two(n):
     """ecl_hip_mul_batch with n one to three below 2^19 / 2^20 / 2^21 on a FRESH context: the scalars-per-thread count R
     (3, 7, 7, 15) does not divide n, so R * ceil(n / R) exceeds the power-of-two capacity the parking buffer used to be
     sized for and the last plane landed outside it (round-2 advisor finding).  Every scalar must come back once with
-    the double-and-add kernel's hash."""
-    import ctypes as C
-    from ecloop_amd import Device, capi
+    the oracle's hash."""
+    from ecloop_amd import Device
     rng = np.random.default_rng(n)
     K = rng.integers(1, 1 << 62, (n, 4), dtype=np.int64).astype(np.uint64)
     d = Device(0)
     try:
         d.set_bloom(ONES)
-        out = np.zeros(n, dtype=capi.FOUND_DTYPE)
-        cnt = C.c_uint32()
-        assert d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, n, C.byref(cnt)) == 0 and cnt.value == n
-        tail = np.arange(n - 4096, n)
-        X, Y = np.zeros((4096, 4), np.uint64), np.zeros((4096, 4), np.uint64)
-        h33, h65 = np.zeros((4096, 5), np.uint32), np.zeros((4096, 5), np.uint32)
-        Kt = np.ascontiguousarray(K[tail])
-        assert d.lib.ecl_hip_diag_mulg(d.h, Kt.ctypes.data, X.ctypes.data, Y.ctypes.data, None, 4096) == 0
-        assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, 4096) == 0
+        assert _mul_all_against_the_oracle(d, K) == n
     finally:
         d.close()
-    recs = out[: cnt.value]
-    order = np.argsort(recs["key_offset"])
-    assert np.array_equal(recs["key_offset"][order], np.arange(n, dtype=np.uint64))
-    assert np.array_equal(recs["h160"][order][tail], h33)  # the scalars parked in the last plane
+
+
+def test_mul_both_address_forms_on_the_long_table_against_the_oracle():
+    """`mul -a cu` (BASELINE configs[4]'s selection) on the 26-bit table the host program moves to: 2^20 random scalars + the digit-edge
+    set, addr33 AND addr65 of every scalar against the oracle."""
+    from ecloop_amd import Device
+    n = (1 << 20) + 333
+    K = _digit_edge_scalars(np.random.default_rng(2026), n, 26)
+    d = Device(0, a33=True, a65=True)
+    try:
+        d.set_bloom(ONES)
+        d.set_mul_window(26)
+        assert _mul_all_against_the_oracle(d, K) == n
+    finally:
+        d.close()
 
 
 def test_pinning_small_and_large_scalar_arrays():
@@ -724,7 +722,7 @@ def test_full_size_range_equals_its_parts_and_the_oracle_on_samples():
     """size-independent properties at BASELINE.json's full size (2^32 keys, addr33): the found set of ONE 2^32-key call equals
     the union of four 2^30-key calls and of 2^29-key calls on a second context with another walk geometry (a GPU's shard
     on 8 GPUs); the hit count is what the filter's density predicts; every hit is confirmed by the oracle's blf_has on the
-    hash the double-and-add kernel derives for that key"""
+    hash the ORACLE derives for that key (orc.mul_hash160_many)"""
     from ecloop_amd import Device
     words = synth_bloom_words(1 << 20, 99, "a")  # density 0.5: 2^32 * 2^-20 = 4096 expected hits
     A = 0x100000000
@@ -747,9 +745,8 @@ def test_full_size_range_equals_its_parts_and_the_oracle_on_samples():
             eighths |= key(recs, A + (q << 29))
         assert eighths == want
         ks = sorted(k for k, _ in want)
-        xs, ys, ok = d.diag_mulg(ks)
-        h33, _ = d.diag_hash160(xs, ys)
-        assert all(ok) and {(k, tuple(int(v) for v in h)) for k, h in zip(ks, h33)} == want
+        h33, _, ok = orc.mul_hash160_many(np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for k in ks], dtype=np.uint64))
+        assert all(ok) and {(k, tuple(int(v) for v in h)) for k, h in zip(ks, h33)} == want  # every hit's hash160 is the oracle's for its key
         flt = orc.OrcFilter(bloom_words=words)
         assert all(flt.check([int(v) for v in h]) for h in h33)
     finally:

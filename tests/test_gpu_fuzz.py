@@ -16,3 +16,12 @@ def test_random_scans_equal_the_oracle(seed):
                         stderr=subprocess.STDOUT, timeout=300)
     out = pr.stdout.decode(errors="replace")
     assert pr.returncode == 0 and "ALL EQUAL" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_random_mul_batches_equal_the_oracle():
+    """a short slice of tools/fuzz_mul_gpu.py: every scalar of every trial against orc.mul_hash160_many (never a device kernel)"""
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_mul_gpu.py"), "12", "31"], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, timeout=600)
+    out = pr.stdout.decode(errors="replace")
+    assert pr.returncode == 0 and "ALL EQUAL" in out, out[-2000:]

@@ -168,24 +168,25 @@ def test_c_abi_error_codes():
     lib.ecl_hip_close(None)  # no-op
 
 
-def test_verify_path_equals_double_and_add_path():
-    """ecl_hip_verify (window-table sum, used as pk_verify_hash for the hits of a call) against the double-and-add
-    kernel + hash kernel and the oracle: random scalars, window edge cases, values >= n, and k = 0 (mod n) flagged"""
+def test_verify_path_equals_the_oracle_and_the_double_and_add_path():
+    """ecl_hip_verify (window-table sum, used as pk_verify_hash for the hits of a call) against the ORACLE for every scalar
+    (orc.mul_hash160_many) and against the device's double-and-add kernel + hash kernel (which therefore is pinned to the oracle on the
+    same 3000 scalars): random scalars, window edge cases, values >= n, and k = 0 (mod n) flagged"""
     import orc
     from ecloop_amd import Device
     rng = np.random.default_rng(21)
     ks = [int.from_bytes(rng.bytes(32), "big") for _ in range(3000)] + [1, 2, 3, orc.N - 1, orc.N + 5, (1 << 256) - 1, (1 << 14) - 1, 1 << 14,
                                                                          1 << 252, 0xDC2A04, 0, orc.N]
+    K = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for k in ks], dtype=np.uint64)
+    w33, w65, wok = orc.mul_hash160_many(K, True, True)
     d = Device(0)
     try:
         h33, h65, ok = d.verify(ks)
         xs, ys, ok2 = d.diag_mulg([k % orc.N for k in ks])
         g33, g65 = d.diag_hash160(xs, ys)
-        assert list(ok) == list(ok2) and list(ok[-2:]) == [0, 0] and all(ok[:-2])
-        assert np.array_equal(h33[:-2], g33[:-2]) and np.array_equal(h65[:-2], g65[:-2])
-        for i in (0, 1, 3000, 3003, 3009):
-            x, y = orc.point_of(ks[i] % orc.N)
-            assert list(h33[i]) == orc.hash160(x, y, True) and list(h65[i]) == orc.hash160(x, y, False)
+        assert list(ok) == list(ok2) == list(wok) and list(ok[-2:]) == [0, 0] and all(ok[:-2])
+        assert np.array_equal(h33[:-2], w33[:-2]) and np.array_equal(h65[:-2], w65[:-2])
+        assert np.array_equal(g33[:-2], w33[:-2]) and np.array_equal(g65[:-2], w65[:-2])
         one = d.verify([0xDC2A04])  # a single key, as after a scan with one hit
         assert list(one[0][0]) == orc.hash160(*orc.point_of(0xDC2A04), True)
     finally:

@@ -253,3 +253,29 @@ def test_mul_flows():
     rc, out, n = orc.mul_batch(orc.OrcFilter(bloom_words=ONES), ks, a33=True, a65=True)
     g = G["mul_dump_cu"]
     assert rc == 0 and n == g["count"] and orc.digest(orc.found_lines(out, n)) == g["sha256_sorted"]
+    # the table form the GPU parity tests use at scale (orc.mul_hash160_many: same jobs, threaded, hashes in input order), pinned to the
+    # same reference dump: its lines for these scalars have the dump's digest
+    K = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for k in ks], dtype=np.uint64)
+    h33, h65, ok = orc.mul_hash160_many(K, True, True, threads=3)
+    assert ok.all()
+    lines = ["addr33\t%s\t%064x" % (orc.hex160(h), k) for h, k in zip(h33, ks)] + ["addr65\t%s\t%064x" % (orc.hex160(h), k) for h, k in zip(h65, ks)]
+    assert orc.digest(lines) == g["sha256_sorted"]
+
+
+def test_mul_hash160_many_on_edge_scalars_and_job_boundaries():
+    """orc.mul_hash160_many against the oracle's double-and-add (orc.point_of, lib/ecc.c:821-853) + addr33/addr65: scalars 0 and n
+    (no point: ok = 0, hashes zeroed, neighbours in the same 2048-scalar job unaffected), values >= n, single digits, a count that
+    is not a multiple of the job size, any thread count"""
+    rnd = random.Random(77)
+    ks = [rnd.getrandbits(256) for _ in range(2048 + 300)]
+    ks[0], ks[1], ks[2047], ks[2048], ks[-1] = 0, orc.N, (1 << 256) - 1, orc.N + 1, 1
+    ks[5:9] = [1 << 14, (1 << 14) - 1, 1 << 252, orc.N - 1]
+    K = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for k in ks], dtype=np.uint64)
+    outs = [orc.mul_hash160_many(K, True, True, threads=t) for t in (1, 5)]
+    for h33, h65, ok in outs:
+        assert list(np.nonzero(ok == 0)[0]) == [0, 1] and not h33[:2].any() and not h65[:2].any()
+        assert np.array_equal(h33, outs[0][0]) and np.array_equal(h65, outs[0][1])
+    h33, h65, ok = outs[0]
+    for i in list(range(2, 12)) + [2046, 2047, 2048, 2049, len(ks) - 1] + [rnd.randrange(len(ks)) for _ in range(40)]:
+        x, y = orc.point_of(ks[i] % orc.N)
+        assert list(h33[i]) == orc.hash160(x, y, True) and list(h65[i]) == orc.hash160(x, y, False), i

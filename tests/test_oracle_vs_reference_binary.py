@@ -91,6 +91,11 @@ def test_mul_matches_the_reference_binary(tmp_path):
     # the reference's tail batch (main.c:467) also emits stale slots beyond the last key: compare the real keys' lines
     want = [l for l in lines if int(l.split("\t")[2], 16) in {k % orc.N for k in ks}]
     assert rc == 0 and sorted(set(want)) == sorted(set(mine)) and len(set(mine)) == 2 * len(set(k % orc.N for k in ks))
+    # and the form the GPU parity tests use at scale
+    K = np.array([[(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for k in ks], dtype=np.uint64)
+    h33, h65, ok = orc.mul_hash160_many(K, True, True)
+    many = ["addr33\t%s\t%064x" % (orc.hex160(h), k % orc.N) for h, k in zip(h33, ks)] + ["addr65\t%s\t%064x" % (orc.hex160(h), k % orc.N) for h, k in zip(h65, ks)]
+    assert ok.all() and sorted(set(many)) == sorted(set(mine))
 
 
 def test_host_program_blf_gen_reads_lines_like_the_reference(tmp_path):

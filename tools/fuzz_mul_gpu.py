@@ -2,10 +2,11 @@
 """Differential fuzz of the `mul` path on the GPU box: random batch sizes (1 .. 2^22+, so that 1, 2, 4, 8 and 16 scalars
 per thread and several staged chunks all occur), random 256-bit scalars with zeros / n / small values mixed in,
 address selections, filters of several sizes and densities, pageable and page-locked scalar arrays, the window width of the
-table fixed at random (8 .. 26 bits) or automatic; every third trial feeds text lines to ecl_hip_mul_batch_raw (`mul -raw`:
+table fixed at random (8 .. 26 bits, now and then 27 .. 29 where the HBM is free) or automatic; every third trial feeds text lines to ecl_hip_mul_batch_raw (`mul -raw`:
 SHA-256 of the line on the device; lengths 0 .. 300, any alignment) with hashlib's digests as the scalars of the yardstick.
-Every hit set of ecl_hip_mul_batch / _raw (window table + ONE inversion per thread) must equal the one derived independently:
-double-and-add kernel -> hash kernel -> the oracle's blf_has on the host.
+Every hit set of ecl_hip_mul_batch / _raw (window table + ONE inversion per thread) must equal the ORACLE's for the same scalars:
+orc.mul_hash160_many (cmd_mul's jobs restated: ec_gtable_mul, one grprdc per 2048 scalars, addr33 / addr65; every scalar of every
+trial, threaded over the host's cores) -> the oracle's blf_has.  No device kernel is the yardstick of another.
 usage: python tools/fuzz_mul_gpu.py [seconds=120] [seed=1]      -> gpurun_out/fuzz_mul.txt"""
 import ctypes as C
 import os
@@ -48,7 +49,9 @@ def main():
             words = synth_bloom_words(nw, 7, "a|b")  # keep the record count of the big batches moderate
         pinned = rnd.random() < 0.5
         host_ptr = None  # pinned: the scalars in page-locked memory from ecl_hip_alloc_host (read by DMA), else a pageable numpy array (staged)
-        window = rnd.choice([0, 0, rnd.randrange(8, 25), rnd.randrange(8, 27)])
+        window = rnd.choice([0, 0, rnd.randrange(8, 25), rnd.randrange(8, 27), rnd.randrange(8, 27), rnd.randrange(8, 27)])
+        if rnd.random() < 0.04:
+            window = rnd.randrange(27, 30)  # 27: 36 GB, 28: 71 GB, 29: 138 GB of table, seconds to build
         raw = trials % 3 == 2
         if raw:  # the scalars ARE the SHA-256 digests of random lines
             import hashlib
@@ -77,7 +80,6 @@ def main():
                 Kp = np.ctypeslib.as_array(C.cast(host_ptr, C.POINTER(C.c_uint64)), shape=K.shape)
                 Kp[:] = K
                 K = Kp
-            assert d.lib.ecl_hip_pin_host(K.ctypes.data, K.nbytes) == 0  # (accepted, does nothing since round 5)
             cap = 2 * n + 16
             out = np.zeros(cap, dtype=capi.FOUND_DTYPE)
             cnt = C.c_uint32()
@@ -85,19 +87,13 @@ def main():
                 rc = d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, int(lens.sum()), table.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
             else:
                 rc = d.lib.ecl_hip_mul_batch(d.h, K.ctypes.data, n, out.ctypes.data, cap, C.byref(cnt))
-            d.lib.ecl_hip_unpin_host(K.ctypes.data)
             assert rc == 0, rc
-            X, Y = np.zeros_like(K), np.zeros_like(K)
-            ok = np.zeros(n, dtype=np.uint8)
-            h33 = np.zeros((n, 5), dtype=np.uint32)
-            h65 = np.zeros((n, 5), dtype=np.uint32)
-            assert d.lib.ecl_hip_diag_mulg(d.h, K.ctypes.data, X.ctypes.data, Y.ctypes.data, ok.ctypes.data, n) == 0
-            assert d.lib.ecl_hip_diag_hash160(d.h, X.ctypes.data, Y.ctypes.data, h33.ctypes.data, h65.ctypes.data, n) == 0
         finally:
             if host_ptr:
                 K = np.array(K)  # the checks below read the scalars after the page-locked copy is gone
                 d.lib.ecl_hip_free_host(host_ptr)
             d.close()
+        h33, h65, ok = orc.mul_hash160_many(K, a33, a65)
         want = set()
         for comp, hh, on in ((1, h33, a33), (0, h65, a65)):
             if not on:
@@ -112,7 +108,7 @@ def main():
             print("MISMATCH", dict(n=n, a33=a33, a65=a65, nw=nw, mode=mode, pinned=pinned, window=window, raw=raw, got=len(got), want=len(want), seed=seed, trial=trials))
             sys.exit(1)
         trials, scalars, hits = trials + 1, scalars + n, hits + len(want)
-    line = "# tools/fuzz_mul_gpu.py %s %d: %d trials, %d scalars, %d compared hits, ALL EQUAL to the double-and-add path + oracle blf_has" % (
+    line = "# tools/fuzz_mul_gpu.py %s %d: %d trials, %d scalars, %d compared hits, ALL EQUAL to the oracle (orc.mul_hash160_many + blf_has on every scalar)" % (
         budget, seed, trials, scalars, hits)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "fuzz_mul.txt"), "w").write(line + "\n")
