@@ -15,9 +15,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libecloop_hip.so")
 ASM = os.path.join(PKG, "libecloop_hip.gfx950.s")  # assembly of the library's code object (kept by the build)
-SOURCES = ["ecloop_hip.hip", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
+SOURCES = ["ecloop_hip.hip", "exports.map", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "abi_lookahead.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
            "bloom.h", "scalar_host.h"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 HOST_SOURCES = ["ecloop_hip_cli.c"]  # the translation unit; its parts (hashed for the stamp like it):
 HOST_PARTS = ["cli_base.h", "cli_filter.h", "cli_report.h", "cli_add.h", "cli_mul.h", "cli_rnd_blf.h", "cli_extras.h"]
 HOST_FLAGS = ["-O2", "-std=gnu11", "-Wall"]
@@ -69,7 +69,7 @@ def build_library(force=False, verbose=False):
     # reads the kernels' static instruction mix from it (bench.py's `roofline.static`, tests/test_profiles_fresh.py)
     tmp = tempfile.mkdtemp(prefix="eclbuild")
     try:
-        cmd = [hipcc] + HIPCC_FLAGS + ["-save-temps", os.path.join(CSRC, "ecloop_hip.hip"), "-o", LIB]
+        cmd = [hipcc] + HIPCC_FLAGS + ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-save-temps", os.path.join(CSRC, "ecloop_hip.hip"), "-o", LIB]
         if verbose:
             print(" ".join(cmd))
         if os.path.exists(LIB + ".stamp"):

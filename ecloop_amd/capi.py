@@ -27,7 +27,7 @@ assert FOUND_DTYPE.itemsize == C.sizeof(Found) == 32
 EXPORTS = [
     "ecl_hip_device_count", "ecl_hip_open", "ecl_hip_close", "ecl_hip_set_bloom", "ecl_hip_set_list", "ecl_hip_reserve", "ecl_hip_add_range",
     "ecl_hip_mul_batch", "ecl_hip_bloom_insert", "ecl_hip_get_bloom", "ecl_hip_set_geometry", "ecl_hip_get_geometry", "ecl_hip_get_timing", "ecl_hip_reset_timing", "ecl_hip_selftest", "ecl_hip_strerror",
-    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_pin_host", "ecl_hip_unpin_host",
+    "ecl_hip_last_error", "ecl_hip_diag_fe", "ecl_hip_diag_mulg", "ecl_hip_diag_hash160", "ecl_hip_diag_bloom", "ecl_hip_diag_bloom_mod", "ecl_hip_set_lookahead", "ecl_hip_set_scan_end", "ecl_hip_get_lookahead_stats",
     "ecl_hip_get_setup_timing", "ecl_hip_get_mul_timing", "ecl_hip_bloom_insert_count", "ecl_hip_alloc_host", "ecl_hip_free_host", "ecl_hip_verify", "ecl_hip_sort_list", "ecl_hip_reserve_mul", "ecl_hip_mul_batch_raw", "ecl_hip_set_mul_window", "ecl_hip_get_mul_window", "ecl_hip_fetch_found", "ecl_hip_plan_geometry",
 ]
 
@@ -67,8 +67,9 @@ def load():
     lib.ecl_hip_reset_timing.argtypes = [P]
     lib.ecl_hip_get_setup_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.ecl_hip_get_mul_timing.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    lib.ecl_hip_pin_host.argtypes = [C.c_void_p, C.c_size_t]
-    lib.ecl_hip_unpin_host.argtypes = [C.c_void_p]
+    lib.ecl_hip_set_lookahead.argtypes = [P, C.c_uint64]
+    lib.ecl_hip_set_scan_end.argtypes = [P, C.c_void_p]
+    lib.ecl_hip_get_lookahead_stats.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ecl_hip_set_mul_window.argtypes = [P, C.c_uint32]
     lib.ecl_hip_reserve_mul.argtypes = [P, C.c_uint32, C.c_uint32]
     lib.ecl_hip_sort_list.argtypes = [P, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -186,6 +187,21 @@ class Device:
         rc = self.lib.ecl_hip_add_range(self.h, s.ctypes.data, nkeys, out.ctypes.data, cap, C.byref(n))
         self._chk(rc, allow=(E_OVERFLOW,))
         return out[: min(n.value, cap)], n.value
+
+    def set_lookahead(self, max_keys):
+        """look-ahead over small contiguous jobs: sweeps of up to max_keys keys (0 = off, else 2^22 .. 2^32; default 2^30)"""
+        self._chk(self.lib.ecl_hip_set_lookahead(self.h, max_keys))
+
+    def set_scan_end(self, end):
+        """hint: the scalar at which the scan stops handing out jobs (None withdraws it)"""
+        e = limbs(end) if end is not None else None
+        self._chk(self.lib.ecl_hip_set_scan_end(self.h, e.ctypes.data if e is not None else None))
+
+    def lookahead_stats(self):
+        """-> (sweeps run by this context, their keys, calls answered from a sweep, their keys)"""
+        v = [C.c_uint64() for _ in range(4)]
+        self._chk(self.lib.ecl_hip_get_lookahead_stats(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def fetch_found(self, first, n):
         """records [first, first + n) of the last add_range / mul_batch call that are still on the device (after an overflow:

@@ -69,6 +69,7 @@ extern "C" int ecl_hip_bloom_insert(ecl_hip* h, const uint32_t (*h160)[5], uint6
   if (!h || (!h160 && n)) return ECL_E_ARG;
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (n == 0) return ECL_OK;
+  la_leave(h), h->la_key_valid = false;  // the resident filter is no longer the one that was uploaded: no shared look-ahead on it
   HIPCHK(h, hipSetDevice(h->dev));
   const u64 chunk = 1ull << 24;  // 320 MB of hashes per upload
   dbuf<u32> dh;
@@ -90,6 +91,7 @@ extern "C" int ecl_hip_bloom_insert_count(ecl_hip* h, const uint32_t (*h160)[5],
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (n == 0) return ECL_OK;
   if (h->bloom_words >= (1ull << (64 - BLF_CHUNK_LOG2 - 6))) return ECL_E_ARG;  // bit position must fit 44 bits (2 TB filter)
+  la_leave(h), h->la_key_valid = false;
   HIPCHK(h, hipSetDevice(h->dev));
   const u64 chunk = 1ull << BLF_CHUNK_LOG2;
   dbuf<u32> dh;

@@ -134,6 +134,7 @@ static int ensure_multable(ecl_hip* h, u32 W) {
   }
   if (h->d_multab) {
     HIPCHK(h, hipStreamSynchronize(h->stream));  // kernels of earlier calls may still read the old table
+    if (h->stream2) HIPCHK(h, hipStreamSynchronize(h->stream2));  // ... on either compute stream (a call that failed between its pieces never joined them)
     release_multable(h);
   }
   h->d_multab = t->d, h->multab_W = W;
@@ -244,7 +245,7 @@ static int mul_setup_auto(ecl_hip* h, u32 n, u32* W_used) {
 }
 
 extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
-  if (!h || n == 0) return ECL_E_ARG;
+  if (!h || n == 0 || cap > ECL_CAP_MAX) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = ensure_found(h, found_words_of(h, raw_cap_of(h, cap ? cap : 1)))) != ECL_OK) return rc;
@@ -254,12 +255,13 @@ extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
 
 extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint32_t n, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
-  if (!h || (!scalars && n) || (!out && cap) || !nout) return ECL_E_ARG;
+  if (!h || (!scalars && n) || (!out && cap) || !nout || cap > ECL_CAP_MAX) return ECL_E_ARG;
   *nout = 0;
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (n == 0) return ECL_OK;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
+  h->last_held = h->last_total = 0, h->last_from_host = false;  // the records of the call before are about to be overwritten
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
   u32 W;
@@ -361,12 +363,13 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
 // context's stream.  Two contexts per GPU overlap one call's copies with the other's kernels, as for ecl_hip_mul_batch.
 extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t text_bytes, const uint64_t* lines, uint32_t n, ecl_found* out,
                                      uint32_t cap, uint32_t* nout) {
-  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_CHUNK || text_bytes > 0xFFFFFFF0u) return ECL_E_ARG;
+  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_CHUNK || text_bytes > 0xFFFFFFF0u || cap > ECL_CAP_MAX) return ECL_E_ARG;
   *nout = 0;
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (n == 0) return ECL_OK;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
+  h->last_held = h->last_total = 0, h->last_from_host = false;
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
   u32 W;

@@ -9,7 +9,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -67,6 +71,17 @@ struct ecl_hip {
   u256 walk_next;  // scalar (mod n) the resident centres are positioned for
   u32 jump_host[16];
   u32 aux_B = 0, aux_T = 0;  // geometry the jump and the ladder in d_aux / jump_host were computed for
+  // look-ahead over a caller's small contiguous jobs (abi_lookahead.h): the group of contexts this one shares sweeps with, the sweep
+  // the last call was served from (ecl_hip_fetch_found reads the rest of that call's records there), the caller's scan end
+  u64 la_max = 0;                              // keys per sweep at most; 0 = off
+  bool geom_fixed = false;                     // the caller set a walk geometry: it wants its calls launched as given
+  std::shared_ptr<struct la_group> grp;
+  bool la_key_valid = false;                   // the filter on the device is the one la_bloom_fp describes
+  u64 la_bloom_fp = 0, la_list_fp = 0;
+  bool la_have_end = false; u256 la_end;
+  std::shared_ptr<struct la_region> last_region; size_t last_host_at = 0; u32 last_host_n = 0; u64 last_host_off = 0; bool last_from_host = false;
+  std::vector<ecl_found> la_buf;
+  uint64_t la_sweeps = 0, la_swept_keys = 0, la_served_calls = 0, la_served_keys = 0;
   // timing
   double kernel_ms = 0, setup_ms = 0, mul_ms = 0;
   uint64_t launches = 0, keys = 0, setups = 0, mul_calls = 0, mul_scalars = 0;
@@ -89,6 +104,10 @@ struct dbuf {
 };
 
 static void release_multable(struct ecl_hip* h);
+static void la_leave(struct ecl_hip* h);
+static void la_filter_changed(struct ecl_hip* h, const uint64_t* bits, uint64_t nwords);
+static void la_list_changed(struct ecl_hip* h, const uint32_t (*h160)[5], uint64_t n);
+static u64 la_default_max();
 
 static void words_of(u32 w[8], const u256& a) {
   for (int i = 0; i < 4; ++i) w[2 * i] = (u32)a.w[i], w[2 * i + 1] = (u32)(a.w[i] >> 32);
@@ -122,7 +141,7 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   int n = ecl_hip_device_count();
   if (device < 0 || device >= n) return ECL_E_NODEV;
   ecl_hip* h = new ecl_hip();
-  h->dev = device, h->flags = flags, h->offs = ord_offs;
+  h->dev = device, h->flags = flags, h->offs = ord_offs, h->la_max = la_default_max();
   *out = h;
   HIPCHK(h, hipSetDevice(device));
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -153,6 +172,7 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
 
 void ecl_hip_close(ecl_hip* h) {
   if (!h) return;
+  la_leave(h);
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -182,29 +202,25 @@ int ecl_hip_set_bloom(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
   if (!h || !bits || nwords == 0 || nwords >= (1ull << 58)) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  la_leave(h), h->la_key_valid = false;
   if (h->d_bloom) HIPCHK(h, hipFree(h->d_bloom));
   h->d_bloom = nullptr, h->bloom_words = 0;
   HIPCHK(h, hipMalloc(&h->d_bloom, nwords * sizeof(u64)));
-  // on the handle's own stream: device threads upload in parallel, each over its own PCIe link; a buffer pinned with
-  // ecl_hip_pin_host goes by DMA at link rate, a pageable one is staged by the runtime
+  // on the handle's own stream: device threads upload in parallel, each over its own PCIe link; memory from ecl_hip_alloc_host goes
+  // by DMA at link rate, a pageable buffer is staged by the runtime
   HIPCHK(h, hipMemcpyAsync(h->d_bloom, bits, nwords * sizeof(u64), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->bloom_words = nwords;
+  la_filter_changed(h, bits, nwords);
   return ECL_OK;
 }
 
-// Page-locking caller memory in place (hipHostRegister) was what these two calls did until round 5; now they accept the buffer and do
-// nothing.  Registering and unregistering memory that the host allocator recycles - next to, or later as, the source or destination of
-// the runtime's own pageable copies, which pin on the fly and remember what they pinned - ends in GPU memory access faults on heap
-// addresses: round 2 saw it a few calls after a 64-byte or 2 KB array had been pinned (small buffers were then left alone), round 5 once
-// in ~2000 fuzz trials with arrays of megabytes, and tools/repro_pin_fault.py gets it within seconds from register / copy / unregister /
-// free cycles, whether the whole buffer or only its whole pages are registered, whether or not the GPU ever reads it - and never
-// without the registration (5000 rounds).  Keeping the ranges registered for good instead made later copies of recycled memory that
-// straddle such a range fail.  Page-locked memory therefore comes from the runtime (ecl_hip_alloc_host = hipHostMalloc, next to the GPU's
-// NUMA node); pageable buffers are copied by the runtime (filter: at the same rate for 54 MB, profiles/r02_bringup.txt) or staged
-// through the library's own pinned buffers (scalar arrays of ecl_hip_mul_batch).
+// Page-locked host memory comes from the runtime (hipHostMalloc, next to the GPU's NUMA node), never from registering the caller's
+// own memory in place: hipHostRegister / hipHostUnregister cycles on memory that the host allocator recycles end in GPU memory access
+// faults inside the ROCm runtime (rounds 2 and 5; tools/repro_pin_fault.py, profiles/r05_pin_fault.txt), which is why the entry points
+// that used to do that are gone.  Pageable buffers are copied by the runtime (filter) or staged through the library's own pinned
+// buffers (scalar arrays of ecl_hip_mul_batch).
 #define ECL_PIN_MIN_BYTES ((size_t)1 << 20)  /* ecl_hip_mul_batch: batches below this are staged whatever their memory is */
-int ecl_hip_pin_host(const void* p, size_t bytes) { return p && bytes ? ECL_OK : ECL_E_ARG; }
 void* ecl_hip_alloc_host(size_t bytes) {
   void* p = nullptr;
   if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
@@ -213,7 +229,6 @@ void* ecl_hip_alloc_host(size_t bytes) {
 void ecl_hip_free_host(void* p) {
   if (p) (void)hipHostFree(p);
 }
-int ecl_hip_unpin_host(const void* p) { return p ? ECL_OK : ECL_E_ARG; }
 
 int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
   if (!h || (n && !h160)) return ECL_E_ARG;
@@ -227,12 +242,15 @@ int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
   }
   HIPCHK(h, hipSetDevice(h->dev));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  la_leave(h);
   if (h->d_list) HIPCHK(h, hipFree(h->d_list));
   h->d_list = nullptr, h->list_n = 0;
+  la_list_changed(h, h160, 0);
   if (n == 0) return ECL_OK;
   HIPCHK(h, hipMalloc(&h->d_list, n * 20));
   HIPCHK(h, hipMemcpy(h->d_list, h160, n * 20, hipMemcpyHostToDevice));
   h->list_n = n;
+  la_list_changed(h, h160, n);
   return ECL_OK;
 }
 
@@ -295,6 +313,7 @@ int ecl_hip_set_geometry(ecl_hip* h, uint32_t half_group, uint32_t max_lanes) {
     h->B = half_group, h->B_auto = false;
   }
   if (max_lanes) h->Tmax = (max_lanes + 255u) & ~255u;
+  if (half_group || max_lanes) h->geom_fixed = true, la_leave(h);
   h->walk_valid = false;
   return ECL_OK;
 }
@@ -338,8 +357,8 @@ static add_kernel_t pick_add_kernel(u32 flags) {
 // without the search kernel running again.
 #define ECL_RAW_CAP_MIN (1u << 20)
 static int ensure_found(ecl_hip* h, u32 cap) {
-  h->last_held = h->last_total = 0;  // every add / mul call comes through here first: the records of the call before are about to be overwritten
   if (cap <= h->found_cap) return ECL_OK;
+  h->last_held = h->last_total = 0;  // the buffer that held the last call's records goes away
   if (h->d_found) HIPCHK(h, hipFree(h->d_found));
   h->d_found = nullptr, h->found_cap = 0;
   HIPCHK(h, hipMalloc(&h->d_found, (size_t)cap * sizeof(ecl_found_dev)));
@@ -348,7 +367,8 @@ static int ensure_found(ecl_hip* h, u32 cap) {
 }
 
 static u32 raw_cap_of(const ecl_hip*, u32 cap) { return cap > ECL_RAW_CAP_MIN ? cap : ECL_RAW_CAP_MIN; }
-static u32 found_words_of(const ecl_hip* h, u32 rcap) { return h->d_list ? 2u * rcap : rcap; }  // records to allocate for a call
+#define ECL_CAP_MAX (1u << 30)  /* records one call can be asked to deliver (32 GB of them); list mode allocates twice the count */
+static u32 found_words_of(const ecl_hip* h, u32 rcap) { return h->d_list ? 2u * rcap : rcap; }  // records to allocate for a call (rcap <= 2^30)
 static void found_to_host(ecl_found* out, const ecl_found_dev* tmp, u32 n, bool keep_endo) {
   for (u32 i = 0; i < n; ++i) {
     out[i].key_offset = tmp[i].key_offset;
@@ -387,9 +407,11 @@ static int collect_found(ecl_hip* h, u32 cap, u32 rcap, ecl_found* out, u32* nou
   return cnt > cap ? ECL_E_OVERFLOW : ECL_OK;
 }
 
+static int la_fetch(ecl_hip* h, uint32_t first, ecl_found* out, uint32_t n, uint32_t* got);
 extern "C" int ecl_hip_fetch_found(ecl_hip* h, uint32_t first, ecl_found* out, uint32_t n, uint32_t* got) {
   if (!h || !got || (!out && n)) return ECL_E_ARG;
   *got = 0;
+  if (h->last_from_host) return la_fetch(h, first, out, n, got);  // the last call was served from a look-ahead sweep: its records are on the host
   if (first >= h->last_held || n == 0) return ECL_OK;
   const u32 take = h->last_held - first < n ? h->last_held - first : n;
   HIPCHK(h, hipSetDevice(h->dev));
@@ -557,7 +579,7 @@ static int ensure_walk_buffers(ecl_hip* h, u32 B, u32 T) {
 static int ensure_gtable(ecl_hip* h);
 
 extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
-  if (!h || nkeys == 0) return ECL_E_ARG;
+  if (!h || nkeys == 0 || cap > ECL_CAP_MAX) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
@@ -571,13 +593,10 @@ extern "C" int ecl_hip_reserve(ecl_hip* h, uint64_t nkeys, uint32_t cap) {
   return ensure_walk_buffers(h, B, T);
 }
 
-extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
-                                 uint32_t* nout) {
-  if (!h || !start || (!out && cap) || !nout) return ECL_E_ARG;
+// one launch of the search kernel over exactly the keys k0, k0 + s, ..., k0 + (nkeys - 1) s  (k0 reduced mod n): the body of
+// ecl_hip_add_range; the look-ahead (abi_lookahead.h) calls it with a sweep instead of the caller's job
+static int add_core(ecl_hip* h, const u256& k0, uint64_t nkeys, ecl_found* out, uint32_t cap, uint32_t* nout) {
   *nout = 0;
-  if (!h->d_bloom) return ECL_E_NOBLOOM;
-  if (nkeys == 0) return ECL_OK;
-  HIPCHK(h, hipSetDevice(h->dev));
   int rc;
   if ((rc = default_lanes(h)) != ECL_OK) return rc;
   if (!nkeys_ok(h, nkeys)) {
@@ -585,6 +604,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
     return ECL_E_ARG;
   }
   if ((rc = ensure_table(h)) != ECL_OK) return rc;
+  h->last_held = h->last_total = 0, h->last_from_host = false;  // the records of the call before are about to be overwritten
   const u32 rcap = raw_cap_of(h, cap ? cap : 1);
   if ((rc = ensure_found(h, found_words_of(h, rcap))) != ECL_OK) return rc;
 
@@ -593,7 +613,6 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   const u64 group = 2ull * B;
   if ((rc = ensure_walk_buffers(h, B, T)) != ECL_OK) return rc;
 
-  u256 k0 = sc_reduce(u256_from(start));
   const u256 s = sc_pow2(h->offs);
   {
     // The walk cannot represent the point at infinity: refuse a scan that contains the scalar 0 (mod n), like the
@@ -686,6 +705,24 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   h->walk_valid = walked == nkeys;
   if (h->walk_valid) h->walk_next = sc_add(k0, sc_mul_u64(s, walked));
   *nout = cnt;
+  return rc;
+}
+
+#include "abi_lookahead.h"
+
+extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
+                                 uint32_t* nout) {
+  if (!h || !start || (!out && cap) || !nout || cap > ECL_CAP_MAX) return ECL_E_ARG;
+  *nout = 0;
+  if (!h->d_bloom) return ECL_E_NOBLOOM;
+  if (nkeys == 0) return ECL_OK;
+  HIPCHK(h, hipSetDevice(h->dev));
+  const u256 k0 = sc_reduce(u256_from(start));
+  bool served = false;
+  int rc = la_add_range(h, k0, nkeys, out, cap, nout, &served);  // a job inside a sweep this context (or one that shares its filter) has run
+  if (served || rc != ECL_OK) return rc;
+  rc = add_core(h, k0, nkeys, out, cap, nout);
+  la_note_plain_call(h, nkeys, *nout);
   return rc;
 }
 

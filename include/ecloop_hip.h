@@ -34,6 +34,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the functions declared here are exported */
+#pragma GCC visibility push(default)
 
 typedef struct ecl_hip ecl_hip; /* opaque per-device context */
 
@@ -77,15 +79,11 @@ void ecl_hip_close(ecl_hip *h);
    filter built from a hash list, utils.c:277-280) into HBM.  May be called again to replace the filter. */
 int ecl_hip_set_bloom(ecl_hip *h, const uint64_t *bits, uint64_t nwords);
 
-/* Kept for callers written against earlier versions: accepted, and nothing is done.  They used to page-lock the caller's buffer in
-   place (hipHostRegister / hipHostUnregister); register / unregister cycles on memory that the host allocator recycles fault inside the
-   ROCm runtime (tools/repro_pin_fault.py; csrc/ecloop_hip.hip has the account).  Page-locked memory comes from ecl_hip_alloc_host. */
-int ecl_hip_pin_host(const void *p, size_t bytes);
-int ecl_hip_unpin_host(const void *p);
 /* Page-locked host memory (hipHostMalloc / hipHostFree): scalar arrays given to ecl_hip_mul_batch from such memory are read by the
    GPU's copy engine directly (57 GB/s), pageable ones go through a staging copy (18 GB/s: 0.57 instead of 1.3 G scalars/s for `mul`).
    The runtime places the pages next to the GPU, which matters on a two-socket host: from the far socket the copy runs at about half
-   the rate (30 against 57 GB/s measured). */
+   the rate (30 against 57 GB/s measured).  (There is no call that page-locks the caller's own memory in place: register / unregister
+   cycles on memory the host allocator recycles fault inside the ROCm runtime - tools/repro_pin_fault.py, profiles/r05_pin_fault.txt.) */
 void *ecl_hip_alloc_host(size_t bytes);
 void ecl_hip_free_host(void *p);
 
@@ -117,11 +115,28 @@ int ecl_hip_set_list(ecl_hip *h, const uint32_t (*h160)[5], uint64_t n);
 /* Hash the nkeys keys  start, start+s, ..., start+(nkeys-1)*s  (s = 2^ord_offs; every encoding / endo variant
    selected at open) and report every bloom hit.  start: 256-bit scalar, 4 little-endian u64 limbs, as `fe`.
    Exactly these keys are tested - the caller reproduces the reference's job rounding (main.c:442,368).
-   Consecutive calls whose `start` continues the previous range reuse the on-device walk state.
+   Consecutive calls whose `start` continues the previous range reuse the on-device walk state; small ones are answered from a
+   look-ahead sweep (ecl_hip_set_lookahead) - same records either way.
    Returns ECL_OK, ECL_E_OVERFLOW (see above) or an error; ECL_E_ARG for an nkeys the geometry cannot walk in one call
    (more than 2^63, or more than 2^32 groups per lane - only reachable with a tiny caller-set geometry). */
 int ecl_hip_add_range(ecl_hip *h, const uint64_t start[4], uint64_t nkeys, ecl_found *out, uint32_t cap,
                       uint32_t *nout);
+
+/* Look-ahead over small contiguous jobs.  The reference's scheduler hands out jobs of 2^21 keys (MAX_JOB_SIZE, main.c:16,418-431): 0.17 ms
+   of work for this GPU, where a launch needs 2^28 keys and more to reach the kernel's rate.  When the ecl_hip_add_range calls of the
+   contexts that share a filter (same flags, stride and filter contents, any device) form that pattern - equal sizes, each starting where
+   the one before ended - a call that finds nothing prepared runs ONE sweep of up to `max_keys` keys from its start, keeps the sweep's hit
+   records on the host and the following calls are answered from them without a launch: each call still receives exactly the hits of its
+   own keys, with key_offset counted from its own start.  Default 2^30 keys (environment ECL_HIP_LOOKAHEAD_LOG2=N, 0 = off);
+   max_keys = 0 turns it off for this context, else 2^22 <= max_keys <= 2^32.  Calls larger than max_keys / 4, contexts with a
+   caller-set geometry (ecl_hip_set_geometry) and filters changed on the device (ecl_hip_bloom_insert) are never looked ahead for. */
+int ecl_hip_set_lookahead(ecl_hip *h, uint64_t max_keys);
+/* Optional hint: the scalar at which the caller's scan stops handing out jobs (ctx->range_e: a worker stops once range_s >= range_e,
+   main.c:420-423); NULL withdraws it.  A sweep then never passes the job that contains `end` - nothing is computed that will not be asked
+   for - and starts with the second contiguous job; without the hint a sweep covers at most half of what the pattern has consumed so far. */
+int ecl_hip_set_scan_end(ecl_hip *h, const uint64_t end[4]);
+/* Measurement: sweeps this context has run and their keys; calls answered from a sweep (this context's or a sharing one's) and their keys. */
+int ecl_hip_get_lookahead_stats(ecl_hip *h, uint64_t *sweeps, uint64_t *swept_keys, uint64_t *served_calls, uint64_t *served_keys);
 
 /* The records of the LAST ecl_hip_add_range / ecl_hip_mul_batch(_raw) call of this context that did not fit its `out`: a call
    keeps up to max(cap, 2^20) records on the device (32 MB), so after ECL_E_OVERFLOW (*nout = total > cap) the caller reads
@@ -227,6 +242,7 @@ int ecl_hip_diag_bloom(ecl_hip *h, const uint32_t (*h160)[5], uint8_t *hit, uint
    device computes it, for any filter size 0 < nwords < 2^58 and x < 2^58; no filter needs to be resident */
 int ecl_hip_diag_bloom_mod(ecl_hip *h, uint64_t nwords, const uint64_t *x, uint64_t *r, uint32_t n);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

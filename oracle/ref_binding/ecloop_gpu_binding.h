@@ -70,6 +70,11 @@ static void gpu_batch_add(ctx_t *ctx, int g, const fe pk, size_t iterations) {
   const uint64_t nkeys = (iterations + GROUP_INV_SIZE - 1) / GROUP_INV_SIZE * GROUP_INV_SIZE;
   gpu_hits_reserve(&hits, 1u << 16);
   uint32_t n = 0;
+  /* where this scan stops handing out jobs (cmd_add_worker leaves its loop at range_s >= range_e, main.c:420; cmd_rnd sets a new range_e
+     per window before it starts the workers, main.c:606-617): lets the library look ahead over the 2^21-key jobs without passing the end */
+  static int tell_end = -1; /* ECLOOP_GPU_NO_SCAN_END=1: measure the look-ahead without the hint (tools/bench_ref_binding.py) */
+  if (tell_end < 0) tell_end = getenv("ECLOOP_GPU_NO_SCAN_END") == NULL;
+  if (tell_end) (void)ecl_hip_set_scan_end(ctx->gpu[g], (const uint64_t *)ctx->range_e);
   int rc = ecl_hip_add_range(ctx->gpu[g], (const uint64_t *)pk, nkeys, hits.rec, hits.cap, &n);
   if (rc == ECL_E_OVERFLOW) { /* e.g. an all-ones filter: every hash is a hit.  The device kept the records that did not fit
                                  (up to max(cap, 2^20) per call): read them; only beyond that is the job run again */

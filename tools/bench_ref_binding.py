@@ -39,7 +39,7 @@ def run(cmd, out, env=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2", type=int, default=34)
-    ap.add_argument("--tag", default="r05")
+    ap.add_argument("--tag", default="r06")
     a = ap.parse_args()
     ref = os.path.join(ROOT, "oracle", "_ref")
     cli = build_host_cli()
@@ -56,24 +56,27 @@ def main():
     rep = ["# tools/bench_ref_binding.py: the reference's host program on the library, add -r %s (2^%d keys), .blf of %d entries (%.0f MB), rates by the reference's status line"
            % (rng, a.log2, bench.FILTER_N, size * 8 / 1e6), "# source_sha256 %s" % source_sha256()]
     want, ws, wt = run([cli, "add", "-f", blf, "-r", rng], os.path.join(tmp, "cli.txt"))
-    rep.append("%-68s: %3d lines %s  wall %5.1f s  status: %s" % ("ecloop-hip (this repository's C host program)", len(want), hashlib.sha256("\n".join(want).encode()).hexdigest()[:12], wt, ws))
+    rep.append("%-78s: %3d lines %s  wall %5.1f s  status: %s" % ("ecloop-hip (this repository's C host program)", len(want), hashlib.sha256("\n".join(want).encode()).hexdigest()[:12], wt, ws))
     ok = True
     legs = [("ecloop_gpu", "MAX_JOB_SIZE 2^21 (unchanged), -t 1", ["-t", "1"], {}),
-            ("ecloop_gpu", "MAX_JOB_SIZE 2^21 (unchanged), -t 2, ECLOOP_GPU_CONTEXTS=2", ["-t", "2"], {"ECLOOP_GPU_CONTEXTS": "2"}),
-            ("ecloop_gpu", "MAX_JOB_SIZE 2^21 (unchanged), -t 4, ECLOOP_GPU_CONTEXTS=4", ["-t", "4"], {"ECLOOP_GPU_CONTEXTS": "4"}),
-            ("ecloop_gpu", "MAX_JOB_SIZE 2^21 (unchanged), -t 8, ECLOOP_GPU_CONTEXTS=8", ["-t", "8"], {"ECLOOP_GPU_CONTEXTS": "8"}),
-            ("ecloop_gpu_j30", "MAX_JOB_SIZE 2^30 (one #define), -t 1", ["-t", "1"], {}),
-            ("ecloop_gpu_j30", "MAX_JOB_SIZE 2^30 (one #define), -t 2, ECLOOP_GPU_CONTEXTS=2", ["-t", "2"], {"ECLOOP_GPU_CONTEXTS": "2"})]
+            ("ecloop_gpu", "2^21, -t 1, scan end not told (ECLOOP_GPU_NO_SCAN_END=1)", ["-t", "1"], {"ECLOOP_GPU_NO_SCAN_END": "1"}),
+            ("ecloop_gpu", "2^21, -t 1, sweeps of 2^32 keys (ECL_HIP_LOOKAHEAD_LOG2=32)", ["-t", "1"], {"ECL_HIP_LOOKAHEAD_LOG2": "32"}),
+            ("ecloop_gpu", "2^21, -t 1, look-ahead OFF (ECL_HIP_LOOKAHEAD_LOG2=0: round 5's library)", ["-t", "1"], {"ECL_HIP_LOOKAHEAD_LOG2": "0"}),
+            ("ecloop_gpu", "2^21, -t 2, ECLOOP_GPU_CONTEXTS=2", ["-t", "2"], {"ECLOOP_GPU_CONTEXTS": "2"}),
+            ("ecloop_gpu", "2^21, -t 4, ECLOOP_GPU_CONTEXTS=4", ["-t", "4"], {"ECLOOP_GPU_CONTEXTS": "4"}),
+            ("ecloop_gpu", "2^21, -t 8, ECLOOP_GPU_CONTEXTS=8", ["-t", "8"], {"ECLOOP_GPU_CONTEXTS": "8"}),
+            ("ecloop_gpu", "2^21, -t 8, ECLOOP_GPU_CONTEXTS=8, look-ahead OFF", ["-t", "8"], {"ECLOOP_GPU_CONTEXTS": "8", "ECL_HIP_LOOKAHEAD_LOG2": "0"}),
+            ("ecloop_gpu_j30", "MAX_JOB_SIZE 2^30 (one #define), -t 1", ["-t", "1"], {})]
     for binary, what, extra, env in legs:
         path = os.path.join(ref, binary)
         if not os.path.exists(path):
-            rep.append("%-68s: binary missing (built by __graft_entry__.build() where /root/reference exists)" % (binary + ", " + what))
+            rep.append("%-78s: binary missing (built by __graft_entry__.build() where /root/reference exists)" % (binary + ", " + what))
             ok = False
             continue
         lines, status, dt = run([path, "add", "-f", blf, "-r", rng] + extra, os.path.join(tmp, "ref.txt"), env)
         same = lines == want
         ok &= same
-        rep.append("%-68s: %3d lines %s  wall %5.1f s  status: %s  found set %s" % (binary + ", " + what, len(lines), hashlib.sha256("\n".join(lines).encode()).hexdigest()[:12], dt, status,
+        rep.append("%-78s: %3d lines %s  wall %5.1f s  status: %s  found set %s" % (binary + ", " + what, len(lines), hashlib.sha256("\n".join(lines).encode()).hexdigest()[:12], dt, status,
                                                                                    "identical" if same else "DIFFERS"))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "%s_ref_binding.txt" % a.tag), "w").write("\n".join(rep) + "\n")

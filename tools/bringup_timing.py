@@ -29,9 +29,13 @@ for geo in [(0, 0), (256, 0), (256, 1 << 20), (1024, 1 << 20)]:
     if geo != (0, 0):
         d.set_geometry(*geo)
     t("set_bloom, pageable host memory", lambda: d.set_bloom(words))
-    capi.load().ecl_hip_pin_host(words.ctypes.data, words.nbytes)
-    t("set_bloom, page-locked host memory", lambda: d.set_bloom(words))
-    capi.load().ecl_hip_unpin_host(words.ctypes.data)
+    import ctypes as C
+    ptr = capi.load().ecl_hip_alloc_host(words.nbytes)
+    pl = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=words.shape)
+    pl[:] = words
+    t("set_bloom, page-locked host memory (ecl_hip_alloc_host)", lambda: d.set_bloom(pl))
+    del pl
+    capi.load().ecl_hip_free_host(ptr)
     t("reserve(2^32 keys): window table, walk table, buffers", lambda: d.reserve(1 << 32))
     t("add_range 2^32 keys, first call", lambda: d.add_range(0x100000000, 1 << 32, cap=1 << 16))
     ms, launches, keys = d.timing()
