@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libecloop_hip.so")
 ASM = os.path.join(PKG, "libecloop_hip.gfx950.s")  # assembly of the library's code object (kept by the build)
-SOURCES = ["ecloop_hip.hip", "exports.map", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "abi_lookahead.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
+SOURCES = ["ecloop_hip.hip", "exports.map", "setup_kernels.h", "mul_kernels.h", "aux_kernels.h", "abi_mul.h", "abi_diag.h", "abi_lookahead.h", "abi_lookahead_ctx.h", "add_kernel.h", "hash160.h", "fe256.h", "ec.h",
            "bloom.h", "scalar_host.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 HOST_SOURCES = ["ecloop_hip_cli.c"]  # the translation unit; its parts (hashed for the stamp like it):

@@ -151,10 +151,22 @@ static u64 pow2floor(u64 v) {
   return v ? r : 0;
 }
 
+// keys from scalar `at` to the nearest sweep held at or after it (0: `at` lies inside one): a new sweep must not run into it
+static u64 la_room(const ecl_hip* h, const la_group& g, const u256& at) {
+  u64 room = ~0ull, o;
+  for (auto& c : g.regions) {
+    if (la_offset(h, at, c->start, &o)) room = o < room ? o : room;
+    else if (la_offset(h, c->start, at, &o) && o < c->nkeys) return 0;
+  }
+  return room;
+}
+
 // keys the next sweep should cover when it starts at scalar `at` (a multiple of the job size n; 0: none)
 static u64 la_plan(const ecl_hip* h, const la_group& g, const u256& at, u64 n) {
   u64 lim = h->la_max / n;  // in jobs
   u64 least = 4;
+  const u64 room = la_room(h, g, at) / n;
+  if (room < lim) lim = room;
   if (h->la_have_end) {
     // keys from `at` to the end as the reference counts them: plain integers (fe_cmp, main.c:420), a last partial stride rounded up
     if (u256_cmp(at, h->la_end) >= 0) return 0;  // the end lies behind: not the scan this hint was given for
@@ -315,14 +327,18 @@ static int la_add_range(ecl_hip* h, const u256& k0, u64 n, ecl_found* out, u32 c
     // one context: the next job starts exactly where the last one ended; several worker threads: their calls arrive a few jobs out of order
     const u64 tol = g.members > 1 ? 4ull * (u64)g.members * n : 0;
     const bool ahead = g.pat && n == g.job_n && la_offset(h, g.next, k0, &gap) && gap <= tol;
-    const bool late = !ahead && g.pat && n == g.job_n && la_offset(h, k0, g.next, &gap) && gap <= tol;
+    // ... or late: a job from before the front that no sweep covers (its worker was slow to call, or it fell between two sweeps)
+    u64 span = 0, o;
+    for (auto& c : g.regions)
+      if (la_offset(h, c->start, g.next, &o) && o > span) span = o;
+    const bool late = !ahead && g.pat && n == g.job_n && la_offset(h, k0, g.next, &gap) && gap <= tol + span;
     if (!ahead && !late) {  // a new pattern starts with this job
       g.pat = true, g.blocked = false, g.job_n = n, g.streak_keys = n, g.hits = g.keys = 0;
       g.next = la_advance(h, k0, n);
       return ECL_OK;
     }
     g.streak_keys += n;
-    if (late) return ECL_OK;  // a job from before the front (its worker was slow to call): launched on its own
+    if (late) return ECL_OK;  // launched on its own
     const u64 L = g.blocked || !la_may_sweep(h, g) ? 0 : la_plan(h, g, k0, n);
     if (!L) {
       g.next = la_advance(h, k0, n);
@@ -339,6 +355,16 @@ static void la_note_plain_call(ecl_hip* h, u64 n, u32 hits) {
   if (!h->grp) return;
   std::lock_guard<std::mutex> lk(h->grp->mu);
   h->grp->hits += hits, h->grp->keys += (double)n;
+}
+
+// ecl_hip_add_range after its argument checks: answered from a sweep, or launched as given
+static int la_dispatch(ecl_hip* h, const u256& k0, u64 nkeys, ecl_found* out, u32 cap, u32* nout) {
+  bool served = false;
+  int rc = la_add_range(h, k0, nkeys, out, cap, nout, &served);  // a job inside a sweep this context (or one that shares its filter) has run
+  if (served || rc != ECL_OK) return rc;
+  rc = add_core(h, k0, nkeys, out, cap, nout);
+  la_note_plain_call(h, nkeys, *nout);
+  return rc;
 }
 
 extern "C" int ecl_hip_set_lookahead(ecl_hip* h, uint64_t max_keys) {

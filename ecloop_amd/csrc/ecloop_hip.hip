@@ -22,6 +22,7 @@
 #include "add_kernel.h"
 #include "ec.h"
 #include "scalar_host.h"
+#include "abi_lookahead_ctx.h"
 #include "setup_kernels.h"
 #include "mul_kernels.h"
 #include "aux_kernels.h"
@@ -71,17 +72,7 @@ struct ecl_hip {
   u256 walk_next;  // scalar (mod n) the resident centres are positioned for
   u32 jump_host[16];
   u32 aux_B = 0, aux_T = 0;  // geometry the jump and the ladder in d_aux / jump_host were computed for
-  // look-ahead over a caller's small contiguous jobs (abi_lookahead.h): the group of contexts this one shares sweeps with, the sweep
-  // the last call was served from (ecl_hip_fetch_found reads the rest of that call's records there), the caller's scan end
-  u64 la_max = 0;                              // keys per sweep at most; 0 = off
-  bool geom_fixed = false;                     // the caller set a walk geometry: it wants its calls launched as given
-  std::shared_ptr<struct la_group> grp;
-  bool la_key_valid = false;                   // the filter on the device is the one la_bloom_fp describes
-  u64 la_bloom_fp = 0, la_list_fp = 0;
-  bool la_have_end = false; u256 la_end;
-  std::shared_ptr<struct la_region> last_region; size_t last_host_at = 0; u32 last_host_n = 0; u64 last_host_off = 0; bool last_from_host = false;
-  std::vector<ecl_found> la_buf;
-  uint64_t la_sweeps = 0, la_swept_keys = 0, la_served_calls = 0, la_served_keys = 0;
+  LA_CONTEXT_MEMBERS
   // timing
   double kernel_ms = 0, setup_ms = 0, mul_ms = 0;
   uint64_t launches = 0, keys = 0, setups = 0, mul_calls = 0, mul_scalars = 0;
@@ -717,13 +708,7 @@ extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t n
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (nkeys == 0) return ECL_OK;
   HIPCHK(h, hipSetDevice(h->dev));
-  const u256 k0 = sc_reduce(u256_from(start));
-  bool served = false;
-  int rc = la_add_range(h, k0, nkeys, out, cap, nout, &served);  // a job inside a sweep this context (or one that shares its filter) has run
-  if (served || rc != ECL_OK) return rc;
-  rc = add_core(h, k0, nkeys, out, cap, nout);
-  la_note_plain_call(h, nkeys, *nout);
-  return rc;
+  return la_dispatch(h, sc_reduce(u256_from(start)), nkeys, out, cap, nout);
 }
 
 #include "abi_mul.h"
