@@ -98,6 +98,31 @@ def build_filter(dev, start, nkeys, filter_n=FILTER_N, ranges=1, cuda_index=0):
     return size, offs, h33
 
 
+def host_cores():
+    """what the box has: logical CPUs online, physical cores (distinct (package, core) pairs of /proc/cpuinfo), sockets, model"""
+    logical = os.cpu_count() or 1
+    cores, sockets, model = set(), set(), None
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "model name" and model is None:
+                model = v
+            elif not k and phys is not None:
+                cores.add((phys, core)), sockets.add(phys)
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core)), sockets.add(phys)
+    except OSError:
+        pass
+    return {"logical": logical, "physical": len(cores) or logical, "sockets": len(sockets) or 1, "model": model, "usable_by_this_process": len(os.sched_getaffinity(0))}
+
+
 def cpu_baseline(words):
     """The UNMODIFIED reference (oracle/_ref, built from /root/reference by oracle/Makefile) on this host's cores, same
     filter, same range start, under every compiler flag set that runs here (SURVEY §7 "CPU baseline fairness": the
@@ -153,12 +178,26 @@ def cpu_baseline(words):
             sets.append({"binary": name, "flags": flags, "error": str(e)[:120]})
             sys.stderr.write(f"[bench] reference baseline {name} failed: {e}\n")
     ran = [x for x in sets if "mkeys" in x]
+    host = host_cores()
     if ran:
         best = max(ran, key=lambda x: x["mkeys"])
-        return {"value": best["mkeys"], "unit": "Mkeys/s", "cores": best["threads"], "kind": "reference",
-                "sample": f"{best['binary']} add -r {RANGE_A:x}:+2^{best['keys_log2']} same .blf, -t {best['threads']} ({best['seconds']}s); "
-                          f"-t 1: {best['single_thread_mkeys']:.2f} Mkeys/s; the other flag sets are in flag_sets",
-                "single_thread_mkeys": best["single_thread_mkeys"], "flag_sets": sets}, sample
+        # ... and that flag set against the thread count (the reference defaults -t to the online CPUs, main.c:833-834): the headline is
+        # the best row of the sweep, `cores` the threads it used, `host_cores` what the box has
+        sweep = [{"threads": best["threads"], "mkeys": best["mkeys"], "keys_log2": best["keys_log2"]}]
+        for t in sorted({32, 128, min(cores, 256)} - {best["threads"]}):
+            if t > cores:
+                continue
+            try:
+                rate, secs, _, _ = run(os.path.join(ROOT, "oracle", "_ref", best["binary"]), 29, t, 120)
+                sweep.append({"threads": t, "mkeys": rate, "keys_log2": 29})
+            except Exception as e:
+                sweep.append({"threads": t, "error": str(e)[:80]})
+        sweep.sort(key=lambda x: x["threads"])
+        top = max((x for x in sweep if "mkeys" in x), key=lambda x: x["mkeys"])
+        return {"value": top["mkeys"], "unit": "Mkeys/s", "cores": top["threads"], "host_cores": host, "kind": "reference",
+                "sample": f"{best['binary']} add -r {RANGE_A:x}:+2^{top['keys_log2']} same .blf, -t {top['threads']} of {host['logical']} logical / "
+                          f"{host['physical']} physical cores (best row of thread_sweep); -t 1: {best['single_thread_mkeys']:.2f} Mkeys/s; the other flag sets are in flag_sets",
+                "single_thread_mkeys": best["single_thread_mkeys"], "thread_sweep": sweep, "flag_sets": sets}, sample
     # fallback: the oracle port (same algorithm, plain C, pthreads)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
@@ -169,7 +208,7 @@ def cpu_baseline(words):
     rc, out, n, checked, hashed = orc.add_range(flt, RANGE_A, RANGE_A + (1 << log2n), verify=False, threads=threads)
     dt = time.time() - t0
     lines = sorted(orc.found_lines(out, n))
-    return {"value": hashed / dt / 1e6, "unit": "Mkeys/s", "cores": threads, "kind": "port",
+    return {"value": hashed / dt / 1e6, "unit": "Mkeys/s", "cores": threads, "host_cores": host, "kind": "port",
             "sample": f"oracle/orc.c add over 2^{log2n} keys, {threads} threads ({dt:.1f}s)", "flag_sets": sets}, (log2n, lines)
 
 
@@ -541,6 +580,37 @@ def bench_add(args, sync, dev_index, emit, t_process):
     out = {order[0]: run_leg(order[0], args.steps, args.warmup)}
     for m in order[1:]:
         out[m] = run_leg(m, min(args.steps, 5), 1)
+    # N = 1 only: the per-GPU shard of the named range at N = 2, 4, 8 as timed steps on THIS GPU (the last shard of each cut; every step
+    # re-positions the walk - set-up kernels, host work and hit handling included, as a rank of an N-GPU run pays them), so that the
+    # projected strong-scaling efficiency is a measured number of this run, not prose.  A projection: N identical GPUs, no host contention.
+    shard_steps = None
+    if world == 1 and headline and args.keys_log2 == 32 and not args.no_secondary and order[0] == "strong":
+        shard_steps = []
+        for n in (2, 4, 8):
+            first, cnt = shard(nkeys, n - 1, n)
+            ks.dev.reserve(cnt)
+
+            def sstep():
+                ks.found.clear()
+                ks.add_keys(RANGE_A + first, cnt)
+
+            sstep()
+            ks.dev.reset_timing()
+            device_fence(dev_index)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                sstep()
+            device_fence(dev_index)
+            dt = (time.perf_counter() - t0) / 5
+            kernel_ms, launches, _ = ks.dev.timing()
+            setup_ms, setups = ks.dev.setup_timing()
+            mine = [RANGE_A + o for o in planted_offs if first <= o < first + cnt]
+            found_pks = {r.pk for r in ks.found}
+            if any(calc_priv(k, 1, 0, 0) not in found_pks for k in mine):
+                raise SystemExit(f"[bench] shard step N={n}: planted keys not found")
+            shard_steps.append({"n_gpus": n, "keys": cnt, "first_key": hex(RANGE_A + first), "steps": 5, "ms_per_step": round(dt * 1e3, 3),
+                                "kernel_ms_per_step": round(kernel_ms / 5, 3), "setup_ms_per_step_on_device": round(setup_ms / 5, 3), "setups": setups,
+                                "geometry": ks.dev.plan_geometry(cnt), "mkeys": round(cnt / dt / 1e6, 1), "planted_checked": len(mine)})
     sync.barrier()  # a worker that aborted above never gets here: the others time out in the barrier, they do not report
     ks.close()
     if rank != 0:
@@ -565,6 +635,14 @@ def bench_add(args, sync, dev_index, emit, t_process):
                    "process_setup": setup, "shards": main_leg["shards"]},
         "roofline": add_roofline(ms_launch, keys_per_launch),
     }
+    if shard_steps:
+        full_ms = main_leg["ms_per_step"]
+        res["shard_steps"] = {"what": "the last contiguous shard of the named 2^32-key range at N = 2 / 4 / 8, timed on this one GPU: 5 steps each, every step "
+                                      "non-contiguous (walk re-positioned), set-up kernels + host work + hit verification inside the timed region",
+                              "full_range_ms_per_step": round(full_ms, 3), "steps": shard_steps,
+                              "projected_efficiency": {str(x["n_gpus"]): round(full_ms / x["n_gpus"] / x["ms_per_step"], 4) for x in shard_steps},
+                              "projected_mkeys": {str(x["n_gpus"]): round(x["n_gpus"] * x["keys"] / x["ms_per_step"] / 1e3, 1) for x in shard_steps},
+                              "label": "PROJECTION from one GPU (N identical GPUs, independent shards, no collective on the data path): not a measured N-GPU run"}
     for m in order[1:]:
         res[m + "_scaling"] = {"value": round(out[m]["value"], 2), "unit": "Mkeys/s", "ms_per_step": round(out[m]["ms_per_step"], 3),
                                "steps": min(args.steps, 5), "keys_per_gpu_per_step": legs[m][1]}

@@ -97,12 +97,25 @@ static void sha256_stream(u32 st[8], const u8 *msg, size_t len) {
   if (total == 128) sha256_block(st, tail + 64);
 }
 
+/* hit records of one device call: the buffer holds MUL_HITS_CAP of them; a call that reports more (ECL_E_OVERFLOW: a dense filter) has
+   kept the rest on the device, fetched here */
+#define MUL_HITS_CAP (1u << 16)
+static ecl_found *mul_collect(run_t *run, int g, int rc, ecl_found *buf, u32 cap, u32 cnt, const char *what) {
+  if (rc == ECL_E_OVERFLOW) {
+    u32 got = 0;
+    buf = realloc(buf, sizeof(ecl_found) * cnt);
+    rc = ecl_hip_fetch_found(run->dev[g], cap, buf + cap, cnt - cap, &got);
+    if (rc == ECL_OK && got != cnt - cap) rc = ECL_E_OVERFLOW; /* more than the device keeps (2^20): the batch sizes below never get there */
+  }
+  if (rc != ECL_OK) die_ecl(run, g, rc, what);
+  return buf;
+}
 static void mul_flush(run_t *run, int g, u64 (*ks)[4], u32 n) {
   if (!n) return;
-  u32 cap = n * 2 + 16, cnt = 0;
+  u32 cap = n * 2 + 16 < MUL_HITS_CAP ? n * 2 + 16 : MUL_HITS_CAP, cnt = 0;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
   int rc = ecl_hip_mul_batch(run->dev[g], ks, n, buf, cap, &cnt);
-  if (rc != ECL_OK) die_ecl(run, g, rc, "mul_batch");
+  buf = mul_collect(run, g, rc, buf, cap, cnt, "mul_batch");
   for (u32 i = 0; i < cnt; ++i) {
     if (!filter_confirms(&run->flt, buf[i].h160)) continue;
     sc pk;
@@ -115,10 +128,10 @@ static void mul_flush(run_t *run, int g, u64 (*ks)[4], u32 n) {
 /* -raw: lines [at, at + n) of a chunk, hashed on the device; a hit's private key is that line's SHA-256, recomputed here */
 static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, const u64 *lines, u32 n) {
   if (!n) return;
-  u32 cap = n * 2 + 16, cnt = 0;
+  u32 cap = n * 2 + 16 < MUL_HITS_CAP ? n * 2 + 16 : MUL_HITS_CAP, cnt = 0;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
   int rc = ecl_hip_mul_batch_raw(run->dev[g], text, (u32)text_len, lines, n, buf, cap, &cnt);
-  if (rc != ECL_OK) die_ecl(run, g, rc, "mul_batch_raw");
+  buf = mul_collect(run, g, rc, buf, cap, cnt, "mul_batch_raw");
   for (u32 i = 0; i < cnt; ++i) {
     if (!filter_confirms(&run->flt, buf[i].h160)) continue;
     const u64 ln = lines[buf[i].key_offset];
@@ -466,12 +479,13 @@ static void raw_grow(const run_t *run, scalar_array *ar, size_t text_bytes, size
 /* The arrays of a run are allocated while the devices come up (bring_up starts mul_prealloc beside the device threads):
    page-locking costs 0.3 ms per MB - 45 ms for the four 33 MB arrays of a one-GPU text run, 90 ms with -bin - which the
    first chunks otherwise wait for one after the other. */
+static size_t mul_largest_batch(const run_t *run, u32 *window);
 static scalar_array mul_ready_arrays[MUL_MAX_ARRAYS];
 static int mul_ready_count;
 typedef struct { const run_t *run; int narr; } mul_prealloc_arg;
 static void *mul_prealloc(void *arg) {
   const mul_prealloc_arg *a = arg;
-  const size_t per = a->run->bin ? MUL_TEXT_CHUNK / 32 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
+  const size_t per = mul_largest_batch(a->run, NULL);
   const bool raw = a->run->opt.raw && !a->run->bin;
   for (int i = 0; i < a->narr && i < MUL_MAX_ARRAYS; ++i) {
     scalar_array ar;
@@ -496,7 +510,7 @@ typedef struct { scalar_queue *q; int g; } mul_dev_arg;
 static void *mul_device_worker(void *arg) {
   mul_dev_arg *a = arg;
   scalar_queue *q = a->q;
-  const size_t STEP = 1u << 22; /* scalars per device call */
+  const size_t STEP = 1u << 22, WHOLE = (size_t)1 << 26; /* lines per -raw call (the ABI's limit); scalars per call otherwise: the array as it is */
   for (;;) {
     pthread_mutex_lock(&q->mu);
     while (!q->nready && !q->done) pthread_cond_wait(&q->cv, &q->mu);
@@ -522,7 +536,7 @@ static void *mul_device_worker(void *arg) {
       for (size_t at = 0; at < ar->n; at += STEP)
         mul_flush_raw(q->run, a->g, ar->text, ar->text_len, ar->lines + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
     else
-      for (size_t at = 0; at < ar->n; at += STEP) mul_flush(q->run, a->g, ar->ks + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
+      for (size_t at = 0; at < ar->n; at += WHOLE) mul_flush(q->run, a->g, ar->ks + at, (u32)(ar->n - at < WHOLE ? ar->n - at : WHOLE));
     pthread_mutex_lock(&q->mu);
     q->idle[q->nidle++] = i;
     pthread_cond_broadcast(&q->cv);
@@ -545,6 +559,127 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
   *t_parse += us_now() - *t_mark, *t_mark = us_now();
   if (all) ar->n = nrec;
   return all;
+}
+/* ---- the usual bulk input, straight from the file: a regular file on stdin whose lines are all 64 hex digits + newline ----
+   Record r of the file is at byte 65 r, so nothing has to be searched, cut or packed: the input is taken in batches of 2^24 records
+   (1.09 GB of text -> one page-locked array of 512 MB = one ecl_hip_mul_batch call, the size at which the device reaches its rate:
+   2^20-scalar calls 0.73, 2^22 0.95, 2^24 1.27 G scalars/s), a batch in slices of 32768 records that the pool's threads take in turn:
+   pread() of the slice into the thread's own 2 MB buffer (a copy out of the page cache without page faults - mapping the file instead
+   made every thread fault its pages in one by one behind the process's one address-space lock: 0.64 G lines/s at 16 threads, less with
+   more; ECLOOP_HIP_MUL_READ=mmap keeps that form for comparison), 16 characters at a time into slot r of the batch's array.  A record
+   that is anything else (another length, '\r', a character that is no hex digit) ends this path at the batch before it: the rest of
+   the input goes through the general reader below, which starts at the file offset this path leaves. */
+#define MUL_BATCH_LOG2 24
+#define MUL_SLICE_RECORDS 32768u
+typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; atomic_bool bad; } fixed_batch;
+typedef struct { fixed_batch *b; size_t first, last; } fixed_file_slice;
+static void *fixed_file_worker(void *arg) {
+#if defined(__x86_64__)
+  fixed_file_slice *s = arg;
+  fixed_batch *b = s->b;
+  if (atomic_load(&b->bad)) return NULL;
+  const size_t bytes = (s->last - s->first) * MUL_RECORD;
+  const char *src;
+  if (b->map) src = b->map + b->base + s->first * MUL_RECORD;
+  else {
+    static __thread char *mine; /* this thread's text buffer, for the life of the command */
+    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS * MUL_RECORD))) { atomic_store(&b->bad, true); return NULL; }
+    for (size_t have = 0; have < bytes;) {
+      ssize_t got = pread(b->fd, mine + have, bytes - have, b->base + (off_t)(s->first * MUL_RECORD + have));
+      if (got <= 0) { atomic_store(&b->bad, true); return NULL; } /* the file shrank under us */
+      have += (size_t)got;
+    }
+    src = mine;
+  }
+  for (size_t r = 0; r < s->last - s->first; ++r) {
+    const char *p = src + r * MUL_RECORD;
+    sc k;
+    if (p[64] != '\n' || !hex16_ssse3(p, &k.w[3]) || !hex16_ssse3(p + 16, &k.w[2]) || !hex16_ssse3(p + 32, &k.w[1]) || !hex16_ssse3(p + 48, &k.w[0])) {
+      atomic_store(&b->bad, true);
+      return NULL;
+    }
+    k = sc_reduce(k);
+    memcpy(b->dst[s->first + r], k.w, 32);
+  }
+#else
+  (void)arg;
+#endif
+  return NULL;
+}
+/* stdin as such a file: the records it holds from the current offset (0: not a regular file, -raw / -bin, no SSSE3, or the first
+   line is not a 64-digit record) */
+static size_t mul_fixed_file_records(const run_t *run, off_t *pos) {
+  struct stat stt;
+  char first[MUL_RECORD];
+  *pos = lseek(0, 0, SEEK_CUR);
+  const char *how = getenv("ECLOOP_HIP_MUL_READ"); /* "chunks": the general reader only (tests compare the two) */
+  if (how && !strcmp(how, "chunks")) return 0;
+  if (run->opt.raw || run->bin || !have_ssse3 || *pos < 0 || fstat(0, &stt) != 0 || !S_ISREG(stt.st_mode) || stt.st_size < *pos + (off_t)MUL_RECORD) return 0;
+  if (pread(0, first, MUL_RECORD, *pos) != (ssize_t)MUL_RECORD || first[64] != '\n') return 0;
+  return (size_t)(stt.st_size - *pos) / MUL_RECORD;
+}
+static size_t mul_batch_records(void) {
+  const char *e = getenv("ECLOOP_HIP_MUL_BATCH_LOG2"); /* experiments */
+  const int l = e && atoi(e) >= 10 && atoi(e) <= 26 ? atoi(e) : MUL_BATCH_LOG2;
+  return (size_t)1 << l;
+}
+
+/* scalars of the largest array a run will hand to a device (bring-up sizes the device staging and the page-locked arrays by it), and
+   the window width worth fixing up front when the input's size is known (st_size / 65 lines): the table is built during bring-up, and
+   a wider one pays from a size on - 22 bits (1.5 GB, 40 ms; 1.11 G scalars/s on 2^24-scalar calls) below 2^28 lines, 24 bits (5.4 GB,
+   +10 ms; 1.17) up to 2^31, 26 bits (19.6 GB, +90 ... 500 ms; 1.27) beyond (profiles/r04_mul_w_sweep.txt); 0 = leave it to the library
+   (22, then 26 after 2^30 scalars: what a pipe gets) */
+static size_t mul_largest_batch(const run_t *run, u32 *window) {
+  off_t pos;
+  const size_t total = mul_fixed_file_records(run, &pos), batch = mul_batch_records();
+  if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
+  if (total) return total < batch ? total : batch;
+  return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
+}
+/* the fixed-record path over stdin from `pos`: batches -> arrays -> device threads; returns the records taken */
+static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
+  const size_t batch = mul_batch_records();
+  const char *how = getenv("ECLOOP_HIP_MUL_READ");
+  const char *map = NULL;
+  if (how && !strcmp(how, "mmap")) { /* comparison: the mapped form */
+    struct stat stt;
+    if (fstat(0, &stt) == 0) map = mmap(NULL, (size_t)stt.st_size, PROT_READ, MAP_PRIVATE, 0, 0);
+    if (map == MAP_FAILED) map = NULL;
+    else madvise((void *)map, (size_t)stt.st_size, MADV_SEQUENTIAL);
+  }
+  static fixed_file_slice fs[((size_t)1 << 26) / MUL_SLICE_RECORDS + 1];
+  size_t done = 0;
+  (void)P;
+  while (done < total) {
+    const size_t nb = total - done < batch ? total - done : batch;
+    u64 t_mark = us_now();
+    pthread_mutex_lock(&sq->mu);
+    while (!sq->nidle) pthread_cond_wait(&sq->cv, &sq->mu);
+    const int ai = sq->idle[--sq->nidle];
+    pthread_mutex_unlock(&sq->mu);
+    *t_array += us_now() - t_mark, t_mark = us_now();
+    scalar_array *ar = &sq->arr[ai];
+    ks_grow(run, ar, nb);
+    *t_grow += us_now() - t_mark, t_mark = us_now();
+    fixed_batch b = {0, map, map ? pos + (off_t)(done * MUL_RECORD) : pos + (off_t)(done * MUL_RECORD), ar->ks, false};
+    int nf = 0;
+    for (size_t at = 0; at < nb; at += MUL_SLICE_RECORDS, ++nf) fs[nf] = (fixed_file_slice){&b, at, at + MUL_SLICE_RECORDS < nb ? at + MUL_SLICE_RECORDS : nb};
+    pool_run(pool, fixed_file_worker, fs, sizeof fs[0], nf);
+    *t_parse += us_now() - t_mark;
+    pthread_mutex_lock(&sq->mu);
+    if (atomic_load(&b.bad)) { /* not such a batch after all: the array goes back, the general reader takes over from here */
+      sq->idle[sq->nidle++] = ai;
+      pthread_mutex_unlock(&sq->mu);
+      break;
+    }
+    ar->n = nb;
+    sq->ready[sq->nready++] = ai;
+    pthread_cond_broadcast(&sq->cv);
+    pthread_mutex_unlock(&sq->mu);
+    done += nb, ++*nbatches;
+  }
+  if (lseek(0, pos + (off_t)(done * MUL_RECORD), SEEK_SET) < 0) { fprintf(stderr, "[!] lseek on the input failed\n"); exit(1); }
+  return done;
 }
 static void cmd_mul(run_t *run) {
   report_restart_clock(&run->rep);
@@ -570,7 +705,6 @@ static void cmd_mul(run_t *run) {
   for (int i = 0; i < mul_ready_count && i < sq.narr; ++i) sq.arr[i] = mul_ready_arrays[i]; /* allocated during bring-up */
   pthread_t reader, devth[MAX_GPUS];
   mul_dev_arg dargs[MAX_GPUS];
-  pthread_create(&reader, NULL, mul_reader, &tq);
   for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
   parse_slice sl[MUL_POOL_MAX];
   memset(sl, 0, sizeof sl);
@@ -579,6 +713,13 @@ static void cmd_mul(run_t *run) {
   pool_t pool;
   pool_init(&pool, P);
   u64 t_text = 0, t_array = 0, t_parse = 0, t_grow = 0, t_pack = 0, nchunks = 0, nfixed = 0, t_mark; /* us per stage (ECLOOP_HIP_STATS) */
+  u64 nbatches = 0, nbatch_records = 0;
+  { /* a file of 64-digit lines: whole batches straight from the file; whatever is left (or is not such a file) goes the general way */
+    off_t pos;
+    const size_t total = mul_fixed_file_records(run, &pos);
+    if (total) nbatch_records = mul_fixed_file_run(run, &pool, P, &sq, pos, total, &t_array, &t_grow, &t_parse, &nbatches);
+  }
+  pthread_create(&reader, NULL, mul_reader, &tq);
   for (;;) {
     t_mark = us_now();
     pthread_mutex_lock(&tq.mu);
@@ -676,7 +817,7 @@ static void cmd_mul(run_t *run) {
   for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp), free(rs[i].tmp);
   if (!run->parse_only) report_close(&run->rep);
   if (getenv("ECLOOP_HIP_STATS")) /* where the front end's wall time went (the main thread drives one chunk at a time) */
-    fprintf(stderr, "mul front end: %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, waiting for a free array (devices behind) %.1f, "
-            "parse / copy %.1f, array growth %.1f, pack %.1f\n", (unsigned long long)nchunks, (unsigned long long)nfixed, P, t_text / 1e3, t_array / 1e3, t_parse / 1e3,
-            t_grow / 1e3, t_pack / 1e3);
+    fprintf(stderr, "mul front end: %llu batches of fixed records straight from the file (%llu lines), %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, "
+            "waiting for a free array (devices behind) %.1f, parse / copy %.1f, array growth %.1f, pack %.1f\n", (unsigned long long)nbatches, (unsigned long long)nbatch_records,
+            (unsigned long long)nchunks, (unsigned long long)nfixed, P, t_text / 1e3, t_array / 1e3, t_parse / 1e3, t_grow / 1e3, t_pack / 1e3);
 }

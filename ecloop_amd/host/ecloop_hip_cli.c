@@ -86,8 +86,10 @@ static void *bringup_thread(void *arg) {
   b->t[3] = us_now();
   if (rc == ECL_OK && b->reserve_keys) rc = ecl_hip_reserve(*h, b->reserve_keys, 4096);
   if (rc == ECL_OK && run->cmd == CMD_MUL && !run->parse_only) { /* window table, staging and record buffer of a usual batch (mul_flush's sizes) */
-    const u32 n = (u32)(run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024);
-    rc = ecl_hip_reserve_mul(*h, n, n * 2 + 16);
+    u32 window = 0;
+    const u32 n = (u32)mul_largest_batch(run, &window);
+    if (window) rc = ecl_hip_set_mul_window(*h, window); /* the input's size is known (a file of 64-digit lines): the table that pays for it */
+    if (rc == ECL_OK) rc = ecl_hip_reserve_mul(*h, n, n * 2 + 16 < MUL_HITS_CAP ? n * 2 + 16 : MUL_HITS_CAP);
   }
   b->t[4] = us_now();
   b->rc = rc;

@@ -1,28 +1,38 @@
 #!/bin/bash
-# `mul` end to end through the C host program (BASELINE.json configs[4]): N seeded 256-bit scalars on stdin, once as
-# 64-hex-digit lines (the reference's input format) and once as 32-byte little-endian scalars (`-bin`).
-#   bash tools/bench_mul_cli.sh [N=16777216]
-N=${1:-16777216}
+# `mul` end to end through the C host program (BASELINE.json configs[4]): N seeded 64-hex-digit lines (the reference's input format,
+# tools/gen_hex_lines.c) in a file on tmpfs, fed (a) as a regular file on stdin, (b) through a pipe (`cat file | ecloop-hip mul`, the
+# reference's usual form, main.c:542-576) and (c) as 32-byte scalars (`-bin`, regular file); rates by the status line (clock starts after
+# bring-up, like the reference's) and by the wall clock of the whole process.
+#   bash tools/bench_mul_cli.sh [LOG2_N=28] [REPS=3] [DIR=/dev/shm]
+L=${1:-28}; REPS=${2:-3}; DIR=${3:-/dev/shm}
+N=$((1 << L))
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-python3 - "$N" <<'PY'
-import sys
-import numpy as np
-n = int(sys.argv[1])
-b = np.frombuffer(np.random.default_rng(7).bytes(n * 32), dtype=np.uint8).reshape(n, 32)
-hexd = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
-t = np.empty((n, 65), dtype=np.uint8)
-t[:, 0:64:2], t[:, 1:64:2], t[:, 64] = hexd[b >> 4], hexd[b & 15], 10
-t.tofile("/tmp/mul_in.txt")
-b[:, ::-1].copy().tofile("/tmp/mul_in.bin")   # big-endian hex digits -> little-endian limbs
-PY
-for mode in txt bin; do
-  flag=""; [ $mode = bin ] && flag="-bin"
-  for rep in 1 2; do
+CLI="$ROOT/ecloop_amd/host/ecloop-hip"
+gcc -O2 -pthread "$ROOT/tools/gen_hex_lines.c" -o /tmp/gen_hex_lines || exit 1
+t0=$(date +%s.%N); /tmp/gen_hex_lines $N 7 $DIR/mul_in.txt 64; t1=$(date +%s.%N)
+echo "# tools/bench_mul_cli.sh $L $REPS $DIR: 2^$L lines ($(du -h $DIR/mul_in.txt | cut -f1)) generated in $(python3 -c "print('%.1f' % ($t1 - $t0))") s; host: $(nproc) hardware threads, $(free -g | awk '/Mem:/{print $2}') GB RAM"
+run() { # label, stdin form, extra env / flags
+  local label=$1 form=$2; shift 2
+  for rep in $(seq 1 $REPS); do
     t0=$(date +%s.%N)
-    ECLOOP_HIP_STATS=1 "$ROOT/ecloop_amd/host/ecloop-hip" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu $flag -q -o /tmp/mul_out.txt < /tmp/mul_in.$mode 2>/tmp/mul_err.txt >/dev/null
+    if [ $form = pipe ]; then cat $DIR/mul_in.txt | env ECLOOP_HIP_STATS=1 "$@" "$CLI" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -q -o /tmp/mul_out.txt 2>/tmp/mul_err.txt >/dev/null
+    else env ECLOOP_HIP_STATS=1 "$@" "$CLI" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -q -o /tmp/mul_out.txt < $DIR/mul_in.txt 2>/tmp/mul_err.txt >/dev/null; fi
     t1=$(date +%s.%N)
     st=$(tr '\r' '\n' < /tmp/mul_err.txt | grep Mkeys | tail -1)
-    tr "\r" "\n" < /tmp/mul_err.txt | grep -E "front end|setup|mul:" | sed "s/^/      /"
-    echo "$mode run $rep, $N scalars: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s (process start-up and GPU bring-up included) | status line: $st"
+    [ $rep = 1 ] && tr "\r" "\n" < /tmp/mul_err.txt | grep -E "front end" | sed "s/^/      /"
+    echo "$label run $rep: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s | status line: $st"
+  done
+}
+run "file  (pread, default)         " file
+run "pipe  (cat file | ecloop-hip)   " pipe
+run "file  (mmap form, round 5)      " file ECLOOP_HIP_MUL_READ=mmap
+run "file  (general reader, 64 MB)   " file ECLOOP_HIP_MUL_READ=chunks
+for T in 8 16 32 64; do run "file  (pread, $T parse threads)  " file ECLOOP_HIP_PARSE_THREADS=$T; done
+echo "# the front end alone (hidden command \`parse\`, nothing printed, no GPU):"
+for T in 8 16 32 64 96; do
+  for m in pread mmap; do
+    t0=$(date +%s.%N); ECLOOP_HIP_PARSE_QUIET=1 ECLOOP_HIP_MUL_READ=$m ECLOOP_HIP_PARSE_THREADS=$T "$CLI" parse < $DIR/mul_in.txt >/dev/null 2>&1; t1=$(date +%s.%N)
+    echo "parse only, $m, $T threads: $(python3 -c "print('%.0f M lines/s' % ($N / ($t1 - $t0) / 1e6))")"
   done
 done
+rm -f $DIR/mul_in.txt
