@@ -19,7 +19,7 @@ SOURCES = ["ecloop_hip.hip", "exports.map", "setup_kernels.h", "mul_kernels.h", 
            "bloom.h", "scalar_host.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden"]
 HOST_SOURCES = ["ecloop_hip_cli.c"]  # the translation unit; its parts (hashed for the stamp like it):
-HOST_PARTS = ["cli_base.h", "cli_filter.h", "cli_report.h", "cli_add.h", "cli_mul.h", "cli_rnd_blf.h", "cli_extras.h"]
+HOST_PARTS = ["cli_base.h", "cli_filter.h", "cli_report.h", "cli_add.h", "cli_mul.h", "cli_rnd_blf.h", "cli_keys.h"]
 HOST_FLAGS = ["-O2", "-std=gnu11", "-Wall"]
 
 

@@ -274,6 +274,9 @@ __device__ __forceinline__ u32 wtab_digit_mem(const u32* __restrict__ kw, const 
 #define ECL_MUL_HOT_GATHERS 0  /* MEASUREMENT BUILD ONLY (wrong points): every gather lands in the first 256 slots of its row, i.e. in cache - the same
                                   instructions and loads without the table's HBM traffic (tools/ab_r05b.sh, tools/ab_r05c.sh) */
 #endif
+#if ECL_MUL_HOT_GATHERS && !defined(ECL_MEASUREMENT_BUILD_WRONG_RESULTS)
+#error "ECL_MUL_HOT_GATHERS computes wrong points: measurement builds only, and they say so with -DECL_MEASUREMENT_BUILD_WRONG_RESULTS"
+#endif
 // How the table points reach the additions, and what was measured about it in round 5 (profiles/r05_mul_lds_gather.txt, commit be22f1e):
 // the point of window w + 1 is requested in the middle of window w's addition and held in 16 VGPRs.  Three deeper forms were built - the
 // point staged in LDS by global_load_lds_dwordx4 (no register held), the wave's scalars staged in LDS a round ahead (digits by ds_read

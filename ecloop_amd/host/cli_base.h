@@ -123,8 +123,39 @@ __attribute__((target("ssse3"))) static bool hex16_ssse3(const char *p, u64 *out
   *out = (u64)_mm_cvtsi128_si64(rev);
   return true;
 }
+/* 32 hex characters -> two little-endian u64 (hi = characters 0..15, lo = 16..31); false if any character is not a hex digit */
+__attribute__((target("avx2"))) static bool hex32_avx2(const char *p, u64 *hi, u64 *lo) {
+  const __m256i c = _mm256_loadu_si256((const __m256i *)p);
+  const __m256i lower = _mm256_or_si256(c, _mm256_set1_epi8(0x20));
+  const __m256i isdig = _mm256_and_si256(_mm256_cmpgt_epi8(c, _mm256_set1_epi8('0' - 1)), _mm256_cmpgt_epi8(_mm256_set1_epi8('9' + 1), c));
+  const __m256i isalp = _mm256_and_si256(_mm256_cmpgt_epi8(lower, _mm256_set1_epi8('a' - 1)), _mm256_cmpgt_epi8(_mm256_set1_epi8('f' + 1), lower));
+  if ((u32)_mm256_movemask_epi8(_mm256_or_si256(isdig, isalp)) != 0xFFFFFFFFu) return false;
+  const __m256i nib = _mm256_add_epi8(_mm256_and_si256(c, _mm256_set1_epi8(0x0F)), _mm256_and_si256(isalp, _mm256_set1_epi8(9)));
+  const __m256i pair = _mm256_maddubs_epi16(nib, _mm256_set1_epi16(0x0110)); /* first digit * 16 + second digit, per 128-bit lane */
+  const __m256i bytes = _mm256_packus_epi16(pair, pair);                      /* each lane: its 8 bytes, most significant first, twice */
+  const __m256i rev = _mm256_shuffle_epi8(bytes, _mm256_setr_epi8(7, 6, 5, 4, 3, 2, 1, 0, -1, -1, -1, -1, -1, -1, -1, -1, 7, 6, 5, 4, 3, 2, 1, 0, -1, -1, -1,
+                                                                  -1, -1, -1, -1, -1));
+  *hi = (u64)_mm256_extract_epi64(rev, 0), *lo = (u64)_mm256_extract_epi64(rev, 2);
+  return true;
+}
+/* a whole 64-digit record -> the scalar's four little-endian u64, stored at dst (32 bytes); false if any character is not a hex digit */
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static bool hex64_avx512(const char *p, u64 *dst) {
+  const __m512i c = _mm512_loadu_si512((const void *)p);
+  const __m512i lower = _mm512_or_si512(c, _mm512_set1_epi8(0x20));
+  const __mmask64 isdig = _mm512_cmpgt_epi8_mask(c, _mm512_set1_epi8('0' - 1)) & _mm512_cmplt_epi8_mask(c, _mm512_set1_epi8('9' + 1));
+  const __mmask64 isalp = _mm512_cmpgt_epi8_mask(lower, _mm512_set1_epi8('a' - 1)) & _mm512_cmplt_epi8_mask(lower, _mm512_set1_epi8('f' + 1));
+  if ((isdig | isalp) != ~(__mmask64)0) return false;
+  const __m512i low = _mm512_and_si512(c, _mm512_set1_epi8(0x0F));
+  const __m512i nib = _mm512_mask_add_epi8(low, isalp, low, _mm512_set1_epi8(9));
+  const __m512i pair = _mm512_maddubs_epi16(nib, _mm512_set1_epi16(0x0110)); /* first digit * 16 + second digit */
+  const __m256i bytes = _mm512_cvtepi16_epi8(pair);                          /* 32 bytes, most significant first */
+  const __m256i rev = _mm256_shuffle_epi8(bytes, _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4,
+                                                                  3, 2, 1, 0));
+  _mm256_storeu_si256((__m256i *)dst, _mm256_permute2x128_si256(rev, rev, 1)); /* all 32 bytes reversed: least significant limb first */
+  return true;
+}
 #endif
-static bool have_ssse3; /* set once in main */
+static bool have_ssse3, have_avx2, have_avx512; /* set once in main */
 
 /* ------------------------------------------------------------------------------------------- command line */
 /* Every option of every command, parsed in ONE pass over argv into this struct: a flag that takes a value consumes the

@@ -319,11 +319,37 @@ static void pool_wake(pool_t *p) {
     pthread_mutex_unlock(&p->mu);
   }
 }
+/* ECLOOP_HIP_PARSE_NODE=N (experiments): the pool's threads run on the CPUs of NUMA node N only (/sys/devices/system/node/nodeN/cpulist) */
+static bool node_cpus(int node, cpu_set_t *set) {
+  char path[96], text[4096];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  const bool got = fgets(text, sizeof text, f) != NULL;
+  fclose(f);
+  if (!got) return false;
+  CPU_ZERO(set);
+  int any = 0;
+  for (char *tok = strtok(text, ",\n"); tok; tok = strtok(NULL, ",\n")) {
+    int a, b;
+    const int k = sscanf(tok, "%d-%d", &a, &b);
+    if (k < 1) continue;
+    if (k == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET(c, set), any = 1;
+  }
+  return any;
+}
 static void pool_init(pool_t *p, int nth) {
   memset(p, 0, sizeof *p);
   pthread_mutex_init(&p->mu, NULL), pthread_cond_init(&p->cv, NULL);
   p->nth = nth;
-  for (int i = 0; i < nth; ++i) p->seat[i] = (pool_seat){p, i}, pthread_create(&p->th[i], NULL, pool_main, &p->seat[i]);
+  cpu_set_t set;
+  const char *node = getenv("ECLOOP_HIP_PARSE_NODE");
+  const bool bind = node && node_cpus(atoi(node), &set);
+  for (int i = 0; i < nth; ++i) {
+    p->seat[i] = (pool_seat){p, i}, pthread_create(&p->th[i], NULL, pool_main, &p->seat[i]);
+    if (bind) pthread_setaffinity_np(p->th[i], sizeof set, &set);
+  }
 }
 static void pool_run(pool_t *p, void *(*fn)(void *), void *args, size_t stride, int n) {
   if (n <= 0) return;
@@ -399,6 +425,9 @@ static void *mul_reader(void *arg) {
       return NULL; /* the mapping stays until exit: the last chunks are still being parsed */
     }
   }
+#ifdef F_SETPIPE_SZ
+  (void)fcntl(0, F_SETPIPE_SZ, 1 << 20); /* a pipe on stdin (`cat keys | ecloop-hip mul`): 1 MB instead of 64 KB in flight, fewer wake-ups of the writer */
+#endif
   char *carry = malloc(q->chunk);
   size_t have = 0;
   for (;;) {
@@ -408,8 +437,11 @@ static void *mul_reader(void *arg) {
     pthread_mutex_unlock(&q->mu);
     c->buf = c->own;
     memcpy(c->buf, carry, have);
-    size_t got;
-    while (have < q->chunk && (got = fread(c->buf + have, 1, q->chunk - have, stdin)) > 0) have += got;
+    for (ssize_t k; have < q->chunk && (k = read(0, c->buf + have, q->chunk - have)) != 0;) { /* (read, not fread: no second copy through stdio) */
+      if (k < 0) { if (errno == EINTR) continue; break; }
+      have += (size_t)k;
+    }
+
     bool eof = have < q->chunk;
     size_t end = have;
     if (!eof) {
@@ -506,12 +538,13 @@ typedef struct {
   pthread_mutex_t mu;
   pthread_cond_t cv;
 } scalar_queue;
-typedef struct { scalar_queue *q; int g; } mul_dev_arg;
+typedef struct { scalar_queue *q; int g; u64 busy_us, wait_us, calls, scalars; } mul_dev_arg; /* (the last four: ECLOOP_HIP_STATS) */
 static void *mul_device_worker(void *arg) {
   mul_dev_arg *a = arg;
   scalar_queue *q = a->q;
   const size_t STEP = 1u << 22, WHOLE = (size_t)1 << 26; /* lines per -raw call (the ABI's limit); scalars per call otherwise: the array as it is */
   for (;;) {
+    u64 t_mark = us_now();
     pthread_mutex_lock(&q->mu);
     while (!q->nready && !q->done) pthread_cond_wait(&q->cv, &q->mu);
     if (!q->nready) { pthread_mutex_unlock(&q->mu); break; }
@@ -519,6 +552,7 @@ static void *mul_device_worker(void *arg) {
     memmove(q->ready, q->ready + 1, sizeof(int) * --q->nready);
     pthread_mutex_unlock(&q->mu);
     scalar_array *ar = &q->arr[i];
+    a->wait_us += us_now() - t_mark, t_mark = us_now(), a->calls++, a->scalars += ar->n;
     if (q->run->parse_only) { /* hidden `parse` command: the scalars as the device would get them, one per line */
       static int quiet = -1; /* ECLOOP_HIP_PARSE_QUIET=1: the front end alone, nothing printed (timing) */
       if (quiet < 0) { const char *e = getenv("ECLOOP_HIP_PARSE_QUIET"); quiet = e && e[0] == '1'; }
@@ -537,6 +571,7 @@ static void *mul_device_worker(void *arg) {
         mul_flush_raw(q->run, a->g, ar->text, ar->text_len, ar->lines + at, (u32)(ar->n - at < STEP ? ar->n - at : STEP));
     else
       for (size_t at = 0; at < ar->n; at += WHOLE) mul_flush(q->run, a->g, ar->ks + at, (u32)(ar->n - at < WHOLE ? ar->n - at : WHOLE));
+    a->busy_us += us_now() - t_mark;
     pthread_mutex_lock(&q->mu);
     q->idle[q->nidle++] = i;
     pthread_cond_broadcast(&q->cv);
@@ -570,8 +605,9 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
    that is anything else (another length, '\r', a character that is no hex digit) ends this path at the batch before it: the rest of
    the input goes through the general reader below, which starts at the file offset this path leaves. */
 #define MUL_BATCH_LOG2 24
-#define MUL_SLICE_RECORDS 32768u
+#define MUL_SLICE_RECORDS_MAX 32768u
 typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; atomic_bool bad; } fixed_batch;
+static atomic_ullong fixed_read_us, fixed_decode_us; /* summed over the pool's threads (ECLOOP_HIP_STATS) */
 typedef struct { fixed_batch *b; size_t first, last; } fixed_file_slice;
 static void *fixed_file_worker(void *arg) {
 #if defined(__x86_64__)
@@ -580,10 +616,11 @@ static void *fixed_file_worker(void *arg) {
   if (atomic_load(&b->bad)) return NULL;
   const size_t bytes = (s->last - s->first) * MUL_RECORD;
   const char *src;
+  const u64 t0 = us_now();
   if (b->map) src = b->map + b->base + s->first * MUL_RECORD;
   else {
     static __thread char *mine; /* this thread's text buffer, for the life of the command */
-    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS * MUL_RECORD))) { atomic_store(&b->bad, true); return NULL; }
+    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS_MAX * MUL_RECORD))) { atomic_store(&b->bad, true); return NULL; }
     for (size_t have = 0; have < bytes;) {
       ssize_t got = pread(b->fd, mine + have, bytes - have, b->base + (off_t)(s->first * MUL_RECORD + have));
       if (got <= 0) { atomic_store(&b->bad, true); return NULL; } /* the file shrank under us */
@@ -591,16 +628,30 @@ static void *fixed_file_worker(void *arg) {
     }
     src = mine;
   }
+  const bool wide = have_avx2, widest = have_avx512;
+  const u64 t1 = us_now();
   for (size_t r = 0; r < s->last - s->first; ++r) {
     const char *p = src + r * MUL_RECORD;
+    u64 *dst = b->dst[s->first + r];
     sc k;
-    if (p[64] != '\n' || !hex16_ssse3(p, &k.w[3]) || !hex16_ssse3(p + 16, &k.w[2]) || !hex16_ssse3(p + 32, &k.w[1]) || !hex16_ssse3(p + 48, &k.w[0])) {
+    if (widest) { /* one load per record; the scalar goes straight to its slot, reduced there in the one case in 2^128 that needs it */
+      if (p[64] == '\n' && hex64_avx512(p, dst)) {
+        if (dst[3] == ~0ull) memcpy(k.w, dst, 32), k = sc_reduce(k), memcpy(dst, k.w, 32);
+        continue;
+      }
+      atomic_store(&b->bad, true);
+      return NULL;
+    }
+    const bool ok = p[64] == '\n' && (wide ? hex32_avx2(p, &k.w[3], &k.w[2]) && hex32_avx2(p + 32, &k.w[1], &k.w[0])
+                                           : hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) && hex16_ssse3(p + 48, &k.w[0]));
+    if (!ok) {
       atomic_store(&b->bad, true);
       return NULL;
     }
     k = sc_reduce(k);
-    memcpy(b->dst[s->first + r], k.w, 32);
+    memcpy(dst, k.w, 32);
   }
+  atomic_fetch_add(&fixed_read_us, t1 - t0), atomic_fetch_add(&fixed_decode_us, us_now() - t1);
 #else
   (void)arg;
 #endif
@@ -647,7 +698,9 @@ static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *
     if (map == MAP_FAILED) map = NULL;
     else madvise((void *)map, (size_t)stt.st_size, MADV_SEQUENTIAL);
   }
-  static fixed_file_slice fs[((size_t)1 << 26) / MUL_SLICE_RECORDS + 1];
+  static fixed_file_slice fs[((size_t)1 << 26) / 4096 + 1];
+  size_t slice = MUL_SLICE_RECORDS_MAX; /* records per slice (2 MB of text; measured: 32768 better than 8192 or 4096 - fewer hand-overs) */
+  { const char *e = getenv("ECLOOP_HIP_MUL_SLICE"); if (e && atoi(e) >= 4096 && atoi(e) <= (int)MUL_SLICE_RECORDS_MAX) slice = (size_t)atoi(e); }
   size_t done = 0;
   (void)P;
   while (done < total) {
@@ -663,7 +716,7 @@ static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *
     *t_grow += us_now() - t_mark, t_mark = us_now();
     fixed_batch b = {0, map, map ? pos + (off_t)(done * MUL_RECORD) : pos + (off_t)(done * MUL_RECORD), ar->ks, false};
     int nf = 0;
-    for (size_t at = 0; at < nb; at += MUL_SLICE_RECORDS, ++nf) fs[nf] = (fixed_file_slice){&b, at, at + MUL_SLICE_RECORDS < nb ? at + MUL_SLICE_RECORDS : nb};
+    for (size_t at = 0; at < nb; at += slice, ++nf) fs[nf] = (fixed_file_slice){&b, at, at + slice < nb ? at + slice : nb};
     pool_run(pool, fixed_file_worker, fs, sizeof fs[0], nf);
     *t_parse += us_now() - t_mark;
     pthread_mutex_lock(&sq->mu);
@@ -705,7 +758,7 @@ static void cmd_mul(run_t *run) {
   for (int i = 0; i < mul_ready_count && i < sq.narr; ++i) sq.arr[i] = mul_ready_arrays[i]; /* allocated during bring-up */
   pthread_t reader, devth[MAX_GPUS];
   mul_dev_arg dargs[MAX_GPUS];
-  for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
+  for (int g = 0; g < run->ngpus; ++g) dargs[g] = (mul_dev_arg){&sq, g, 0, 0, 0, 0}, pthread_create(&devth[g], NULL, mul_device_worker, &dargs[g]);
   parse_slice sl[MUL_POOL_MAX];
   memset(sl, 0, sizeof sl);
   static raw_slice rs[MUL_POOL_MAX];
@@ -809,15 +862,25 @@ static void cmd_mul(run_t *run) {
   pool_stop(&pool);
   pthread_join(reader, NULL);
   for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
+  if (!run->parse_only) report_close(&run->rep); /* the search is over here: giving back page-locked arrays (0.1 ms per MB) is not part of it */
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
-  for (int i = 0; i < sq.narr; ++i) {
-    ks_free(run, sq.arr[i].ks, sq.arr[i].pinned);
-    raw_release(sq.arr[i].text, sq.arr[i].text_pinned), raw_release(sq.arr[i].lines, sq.arr[i].lines_pinned);
+  for (int i = 0; i < sq.narr; ++i) { /* (page-locked arrays are left to the end of the process, which follows: unlocking 2 GB takes 0.2 s) */
+    if (!sq.arr[i].pinned) ks_free(run, sq.arr[i].ks, false);
+    if (!sq.arr[i].text_pinned) raw_release(sq.arr[i].text, false);
+    if (!sq.arr[i].lines_pinned) raw_release(sq.arr[i].lines, false);
   }
   for (int i = 0; i < MUL_POOL_MAX; ++i) free(sl[i].tmp), free(rs[i].tmp);
-  if (!run->parse_only) report_close(&run->rep);
+  if (getenv("ECLOOP_HIP_STATS") && !run->parse_only)
+    for (int g = 0; g < run->ngpus; ++g) {
+      double ms = 0;
+      uint64_t calls = 0, n = 0;
+      ecl_hip_get_mul_timing(run->dev[g], &ms, &calls, &n);
+      fprintf(stderr, "mul context %d: %llu arrays, %llu scalars, %.1f ms in device calls (%.1f ms by the library's events over %llu calls), %.1f ms waiting for parsed input\n", g,
+              (unsigned long long)dargs[g].calls, (unsigned long long)dargs[g].scalars, dargs[g].busy_us / 1e3, ms, (unsigned long long)calls, dargs[g].wait_us / 1e3);
+    }
   if (getenv("ECLOOP_HIP_STATS")) /* where the front end's wall time went (the main thread drives one chunk at a time) */
     fprintf(stderr, "mul front end: %llu batches of fixed records straight from the file (%llu lines), %llu chunks (%llu of fixed 65-byte records), %d pool threads; ms waiting for text %.1f, "
-            "waiting for a free array (devices behind) %.1f, parse / copy %.1f, array growth %.1f, pack %.1f\n", (unsigned long long)nbatches, (unsigned long long)nbatch_records,
-            (unsigned long long)nchunks, (unsigned long long)nfixed, P, t_text / 1e3, t_array / 1e3, t_parse / 1e3, t_grow / 1e3, t_pack / 1e3);
+            "waiting for a free array (devices behind) %.1f, parse / copy %.1f (threads' sum: reading %.1f, decoding %.1f), array growth %.1f, pack %.1f\n", (unsigned long long)nbatches,
+            (unsigned long long)nbatch_records, (unsigned long long)nchunks, (unsigned long long)nfixed, P, t_text / 1e3, t_array / 1e3, t_parse / 1e3,
+            atomic_load(&fixed_read_us) / 1e3, atomic_load(&fixed_decode_us) / 1e3, t_grow / 1e3, t_pack / 1e3);
 }

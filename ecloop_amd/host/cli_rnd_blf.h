@@ -241,10 +241,7 @@ static void usage(const char *prog) { /* the reference's help text (main.c:750-7
       "  -bin            - mul: stdin carries 32-byte little-endian scalars instead of hex lines\n",
       "\nOther commands:\n",
       "  blf-gen         - create bloom filter from list of hex-encoded hash160\n",
-      "  blf-check       - check bloom filter for given hex-encoded hash160\n",
-      "  bench           - run benchmark of the device paths (add per address type / endo, mul)\n",
-      "  bench-gtable    - run benchmark of ecc multiplication (with different table size)\n",
-      "  mult-verify     - check the window-table multiplication against double-and-add (2 .. 16001)\n\n"};
+      "  blf-check       - check bloom filter for given hex-encoded hash160\n\n"};
   printf("Usage: %s <cmd> [-t <gpus>] [-f <file>] [-a <addr_type>] [-r <range>]\nv%s ~ MI355X build of the ecloop command set\n", prog, VERSION);
   for (size_t i = 0; i < sizeof TEXT / sizeof TEXT[0]; ++i) fputs(TEXT[i], stdout);
 }

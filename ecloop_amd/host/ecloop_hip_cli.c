@@ -16,6 +16,7 @@
  */
 #define _GNU_SOURCE
 #include <ctype.h>
+#include <errno.h>
 #include <locale.h>
 #include <math.h>
 #include <pthread.h>
@@ -56,7 +57,7 @@ typedef struct { u64 w[4]; } sc; /* 256-bit scalar, little-endian limbs (the ref
 #include "cli_add.h"
 #include "cli_mul.h"
 #include "cli_rnd_blf.h"
-#include "cli_extras.h"
+#include "cli_keys.h"
 
 /* ------------------------------------------------------------------------------------------- device bring-up */
 /* Device contexts of a run: context g works on GPU (g mod shown) mod real, where `shown` is the -t count clamped to
@@ -145,6 +146,8 @@ int main(int argc, const char **argv) {
   hexval_init();
 #if defined(__x86_64__)
   have_ssse3 = __builtin_cpu_supports("ssse3");
+  have_avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && !getenv("ECLOOP_HIP_NO_AVX512");
+  have_avx2 = __builtin_cpu_supports("avx2") && !getenv("ECLOOP_HIP_NO_AVX2"); /* (the variable: tests run the SSSE3 form on a CPU that has both) */
 #endif
   static run_t run;
   opts_t *o = &run.opt;
@@ -153,9 +156,6 @@ int main(int argc, const char **argv) {
   /* commands that need no search context */
   if (!strcmp(verb, "blf-gen")) return cmd_blf_gen(o, argv[0]), 0;
   if (!strcmp(verb, "blf-check")) return cmd_blf_check(o, argc, argv), 0;
-  if (!strcmp(verb, "bench")) return run_bench(o);
-  if (!strcmp(verb, "bench-gtable")) return run_bench_gtable();
-  if (!strcmp(verb, "mult-verify")) return run_mult_verify();
   if (!strcmp(verb, "parse")) { /* hidden: `mul`'s text front end alone (no GPU), for the parser tests */
     run.cmd = CMD_MUL, run.parse_only = true, run.ngpus = 1, run.bin = o->bin;
     report_init(&run.rep, NULL, true);

@@ -172,22 +172,6 @@ def test_long_hash_list_prepared_on_the_device(cli, tmp_path):
 
 
 @pytest.mark.gpu
-def test_mult_verify_and_bench_gtable_commands(cli):
-    """the reference's `mult-verify` (lib/bench.c:143-166: silent, exit 0 when the window-table products equal the
-    double-and-add ones for 2 .. 16001) and `bench-gtable` (lib/bench.c:114-141: one line per window width, same format)"""
-    pr = subprocess.run([cli, "mult-verify"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert pr.returncode == 0 and pr.stdout == b"", pr.stdout + pr.stderr
-    pr = subprocess.run([cli, "bench-gtable"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    rows = pr.stdout.decode().splitlines()
-    assert pr.returncode == 0 and len(rows) == 10, pr.stdout + pr.stderr
-    for w, row in zip(range(8, 28, 2), rows):
-        m = re.fullmatch(r"w=(\d\d): ([\d.]+)K it/s \| gen: +([\d.]+)s \| mul: +([\d.]+)s \| mem: +([\d.]+)MB", row)
-        assert m and int(m.group(1)) == w and float(m.group(2)) > 1000, row
-    # w = 14, signed digits: 18 rows of 8192 points + the 4-bit last window's 16 (the reference allocates 19 rows of 16383: 19.0 MB)
-    assert abs(float(re.search(r"mem: +([\d.]+)MB", rows[3]).group(1)) - 9.0) < 0.1
-
-
-@pytest.mark.gpu
 def test_mul_flows(cli, tmp_path):
     lines, status, _ = run(cli, ["mul", "-f", os.path.join(GOLD, "btc-bw-hash"), "-a", "cu"], stdin_path=os.path.join(GOLD, "btc-bw-priv"),
                            out=str(tmp_path / "m.txt"))
@@ -561,6 +545,48 @@ def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
     for i in list(range(0, n, 9973)) + [n - 1, 1032444, 1032445, 1032446]:
         v = int.from_bytes(b[i].tobytes(), "big")
         assert int(out[i], 16) == (v - N if v >= N else v), i
+
+
+@pytest.mark.parametrize("decoder", ["avx512", "avx2", "ssse3"])
+def test_mul_parser_file_of_64_digit_lines_in_batches(cli, tmp_path, decoder):
+    """a regular file of 64-digit lines on stdin is taken in batches straight from the file (cli_mul.h: pread slices, one decoder per
+    instruction set: a whole record per AVX-512 load, two AVX2 halves, four SSSE3 quarters) - against fe_modn_from_hex in python ints and
+    against the general reader on the same bytes: random values, upper case, values >= n (reduced; top limb all ones is the AVX-512 form's
+    slow case), a batch count that does not divide the file; then the same file with a record that is no such line in the middle (the
+    path stops at the batch before it, the general reader takes over) and with a short line + a last line without newline."""
+    import random
+    r = random.Random(9)
+    N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    vals = [r.getrandbits(256) for _ in range(50000)]
+    vals[7], vals[8], vals[9], vals[10], vals[11] = N, N - 1, (1 << 256) - 1, N + 12345, ((1 << 64) - 1) << 192
+    lines = [("%064x" % v).upper() if i % 5 == 3 else "%064x" % v for i, v in enumerate(vals)]
+    env = dict(os.environ, ECLOOP_HIP_MUL_BATCH_LOG2="13", ECLOOP_HIP_MUL_SLICE="4096")
+    if decoder != "avx512":
+        env["ECLOOP_HIP_NO_AVX512"] = "1"
+    if decoder == "ssse3":
+        env["ECLOOP_HIP_NO_AVX2"] = "1"
+
+    def parse(path, **more):
+        pr = subprocess.run([cli, "parse"], stdin=open(path, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=300,
+                            env=dict(env, ECLOOP_HIP_STATS="1", **more))
+        return pr.stdout.decode().split(), pr.stderr.decode()
+
+    clean = tmp_path / "clean.txt"
+    clean.write_text("".join(l + "\n" for l in lines))
+    got, stats = parse(str(clean))
+    assert got == ["%064x" % (v % N) for v in vals]
+    assert "7 batches of fixed records straight from the file (50000 lines)" in stats  # 6 x 8192 + 848
+    assert parse(str(clean), ECLOOP_HIP_MUL_READ="chunks")[0] == got and parse(str(clean), ECLOOP_HIP_MUL_READ="mmap")[0] == got
+    odd = list(lines)
+    odd[30000] = "0x" + odd[30000][:40]            # a 42-character line in the fourth batch
+    odd[30001] = odd[30001][:63] + "g"             # 64 characters, one of them no hex digit (skipped by fe_modn_from_hex)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("".join(l + "\n" for l in odd) + "abc\n" + lines[0])  # ... a short line and a last line without newline
+    got, stats = parse(str(bad))
+    want, _ = parse(str(bad), ECLOOP_HIP_MUL_READ="chunks")
+    assert got == want and len(got) == 50002 and got[-1] == "%064x" % (vals[0] % N) and got[-2] == "%064x" % 0xABC
+    assert got[30000] == "%064x" % int(odd[30000][2:], 16) and got[30001] == "%064x" % int(odd[30001][:63], 16)
+    assert "3 batches of fixed records straight from the file (24576 lines)" in stats
 
 
 @pytest.mark.gpu

@@ -3,8 +3,8 @@
 # tools/gen_hex_lines.c) in a file on tmpfs, fed (a) as a regular file on stdin, (b) through a pipe (`cat file | ecloop-hip mul`, the
 # reference's usual form, main.c:542-576) and (c) as 32-byte scalars (`-bin`, regular file); rates by the status line (clock starts after
 # bring-up, like the reference's) and by the wall clock of the whole process.
-#   bash tools/bench_mul_cli.sh [LOG2_N=28] [REPS=3] [DIR=/dev/shm]
-L=${1:-28}; REPS=${2:-3}; DIR=${3:-/dev/shm}
+#   bash tools/bench_mul_cli.sh [LOG2_N=30] [REPS=3] [DIR=/dev/shm]      (2^30 lines = 70 GB of text: a timed window of about a second)
+L=${1:-30}; REPS=${2:-3}; DIR=${3:-/dev/shm}
 N=$((1 << L))
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CLI="$ROOT/ecloop_amd/host/ecloop-hip"
@@ -19,17 +19,20 @@ run() { # label, stdin form, extra env / flags
     else env ECLOOP_HIP_STATS=1 "$@" "$CLI" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -q -o /tmp/mul_out.txt < $DIR/mul_in.txt 2>/tmp/mul_err.txt >/dev/null; fi
     t1=$(date +%s.%N)
     st=$(tr '\r' '\n' < /tmp/mul_err.txt | grep Mkeys | tail -1)
-    [ $rep = 1 ] && tr "\r" "\n" < /tmp/mul_err.txt | grep -E "front end" | sed "s/^/      /"
+    [ $rep = 1 ] && tr "\r" "\n" < /tmp/mul_err.txt | grep -E "front end|mul context" | sed "s/^/      /"
     echo "$label run $rep: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s | status line: $st"
   done
 }
+echo "# (one untimed pass first: the first read of freshly written tmpfs pages runs at a fifth of the rate of the following ones)"
+env "$CLI" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -q -o /tmp/mul_out.txt < $DIR/mul_in.txt >/dev/null 2>&1
 run "file  (pread, default)         " file
 run "pipe  (cat file | ecloop-hip)   " pipe
 run "file  (mmap form, round 5)      " file ECLOOP_HIP_MUL_READ=mmap
 run "file  (general reader, 64 MB)   " file ECLOOP_HIP_MUL_READ=chunks
-for T in 8 16 32 64; do run "file  (pread, $T parse threads)  " file ECLOOP_HIP_PARSE_THREADS=$T; done
+run "file  (AVX2 decoder)            " file ECLOOP_HIP_NO_AVX512=1
+for T in 8 24 32; do run "file  (pread, $T parse threads)  " file ECLOOP_HIP_PARSE_THREADS=$T; done
 echo "# the front end alone (hidden command \`parse\`, nothing printed, no GPU):"
-for T in 8 16 32 64 96; do
+for T in 8 16 32; do
   for m in pread mmap; do
     t0=$(date +%s.%N); ECLOOP_HIP_PARSE_QUIET=1 ECLOOP_HIP_MUL_READ=$m ECLOOP_HIP_PARSE_THREADS=$T "$CLI" parse < $DIR/mul_in.txt >/dev/null 2>&1; t1=$(date +%s.%N)
     echo "parse only, $m, $T threads: $(python3 -c "print('%.0f M lines/s' % ($N / ($t1 - $t0) / 1e6))")"
