@@ -284,7 +284,8 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, b
 #endif
 #ifndef ECL_ADD_WAVES
 #define ECL_ADD_WAVES 4  /* measured early in the round: 2 -> 8.38, 3 -> 8.99, 4 -> 7.97 Gkeys/s (addr33); final kernel: 2 is 2 % slower, 5 is 0.9 % and 6 is 4.8 % slower,
-                           4 is 0.2-0.5 % faster than 3 except for -a cu -endo (0.4 % slower: it stays at 3) */
+                           4 is 0.2-0.5 % faster than 3 except for -a cu -endo (0.4 % slower: it stays at 3); -a u -endo spills inside its per-point loop at 4
+                           (17 scratch instructions per table point), so it takes 3 as well (round 6) */
 #endif
 // threads per workgroup of the add kernel.  Waves never talk to each other (no barrier, wave-private LDS rings), so the
 // only thing the size decides is the granularity at which the dispatcher hands out work: 64 / 128 / 256 measured equal
@@ -293,7 +294,7 @@ __device__ __forceinline__ void check_point(const add_args& a, cand_queues* q, b
 #define ECL_ADD_BLOCK 256
 #endif
 template <bool A33, bool A65, bool ENDO>
-__global__ void __launch_bounds__(ECL_ADD_BLOCK, (A33 && A65 && ENDO) ? 3 : ECL_ADD_WAVES) k_add(const add_args a) {
+__global__ void __launch_bounds__(ECL_ADD_BLOCK, (A65 && ENDO) ? 3 : ECL_ADD_WAVES) k_add(const add_args a) {
   __shared__ u32 q_mem[ECL_ADD_BLOCK / 64][2][8 * ECL_Q_SLOTS];  // two candidate rings per wave
   cand_queues q;
   q.a.mem = q_mem[threadIdx.x >> 6][0], q.a.head = 0, q.a.count = 0;

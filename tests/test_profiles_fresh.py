@@ -96,3 +96,38 @@ def test_static_mix_of_the_mul_kernel_matches_its_profile():
     else:
         est, pmc = m["per_scalar_static"]["valu"], prof["derived"]["valu_lane_ops_per_scalar"]
         assert 0.90 < est / pmc < 1.05, (est, pmc)  # the static estimate leaves the inversion's share out and counts rarely taken ring blocks
+
+
+def test_every_instantiation_is_fingerprinted_and_keeps_scratch_out_of_its_loops():
+    """all six k_add instantiations (-a c / u / cu, each with and without -endo) and the three of k_mul_check, not only the headline
+    kernel: (1) structural - no scratch (spill) instruction inside a per-key or per-table-point loop (k_add: prefix-product, table and
+    `which` loops; k_mul_check: window loop, per-scalar sum loop outside the call of the out-of-line complete sum, walk-back loop);
+    what remains sits in the once-per-group launch loop, or passes arguments to the rarely taken complete sum; (2) the tracked
+    profiles/rNN_static_mix.json (tools/isa_mix.py --all: fingerprints, registers, spills) describes the library that is being built -
+    a drift warns, and fails under ECL_REQUIRE_FRESH_PROFILES=1, like the PMC profiles above"""
+    from ecloop_amd.build import ASM, build_library
+    import isa_mix
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        build_library()
+    if not os.path.exists(ASM):
+        pytest.skip("no hipcc and no kept assembly: nothing to analyse")
+    now = isa_mix.analyse_all(ASM)
+    assert set(now) == set(isa_mix.ADD_KERNELS) | set(isa_mix.MUL_KERNELS)
+    for label, a in now.items():
+        loops = a["scratch_in_loops"]
+        inner = {k: v for k, v in loops.items() if k not in ("launch", "sum_at_the_call_of_the_complete_sum")}
+        assert all(v == 0 for v in inner.values()), (label, loops)
+        assert a["registers"]["vgpr_count"] in (128, 168), (label, a["registers"])  # 4 / 3 waves per SIMD
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_static_mix.json")))
+    assert files, "no profiles/rNN_static_mix.json: python tools/isa_mix.py --all > profiles/rNN_static_mix.json"
+    kept = json.load(open(files[-1]))
+    stale = []
+    for label, a in now.items():
+        want = kept.get(label, {}).get("fingerprint", {})
+        stale += [f"{label} {k}: built {a['fingerprint'].get(k)} vs {v}" for k, v in want.items() if abs(a["fingerprint"].get(k, 0) - v) > max(0.01 * v, 1)]
+        if not want:
+            stale.append(f"{label}: not in {os.path.basename(files[-1])}")
+    if stale:
+        msg = f"{os.path.basename(files[-1])} describes another build ({'; '.join(stale[:6])}): python tools/isa_mix.py --all > profiles/rNN_static_mix.json"
+        assert os.environ.get("ECL_REQUIRE_FRESH_PROFILES") != "1", msg
+        warnings.warn(msg)

@@ -19,7 +19,7 @@ What the numbers are used for:
     blocks, so it is an UPPER estimate) + half a trip of the table loop around it and of the prefix-product loop
     (each serves two keys).  The PMC count SQ_INSTS_VALU is the truth for the total; the class SHARES come from here.
 
-usage: tools/isa_mix.py [file.s] [mangled kernel name] [--json]"""
+usage: tools/isa_mix.py [file.s] [mangled kernel name] [--json]     |     tools/isa_mix.py --all   (every instantiation: profiles/rNN_static_mix.json)"""
 import json
 import os
 import re
@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASM = os.path.join(ROOT, "ecloop_amd", "libecloop_hip.gfx950.s")
 K_ADD33 = "_Z5k_addILb1ELb0ELb0EEv8add_args"
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_not_b32", "v_bitop3_b32"}
-KEYS = ("valu", "mad64", "fast", "other", "salu", "smem", "vmem", "lds", "scratch")
+KEYS = ("valu", "mad64", "fast", "other", "salu", "smem", "vmem", "lds", "scratch", "call", "scratch_at_calls")
 
 
 def classify(op):
@@ -57,6 +57,8 @@ def add_to(c, op):
         c["smem"] += 1
     elif op.startswith("s_"):
         c["salu"] += 1
+        if op.startswith("s_swappc"):
+            c["call"] += 1
 
 
 def blocks(path, kernel):
@@ -94,6 +96,9 @@ def blocks(path, kernel):
             add_to(cur["c"], mm.group(1))
         i += 1
     out.append(cur)
+    for blk in out:  # a block that calls an out-of-line function passes its arguments through scratch: not spill traffic of the loop it sits in
+        if blk["c"]["call"]:
+            blk["c"]["scratch_at_calls"], blk["c"]["scratch"] = blk["c"]["scratch"], 0
     return out, s[b : b + 4000]
 
 
@@ -151,7 +156,7 @@ def analyse(path=ASM, kernel=K_ADD33):
             res["per_key_static"] = est
             res["fingerprint"] = {"kernel_valu": total["valu"], "which_loop_valu": excl[W]["valu"], "which_loop_mad64": excl[W]["mad64"],
                                   "which_loop_fast": excl[W]["fast"], "table_loop_valu": excl[T]["valu"],
-                                  "prefix_loop_valu": res.get("prefix_loop", zero())["valu"], "scratch_instr": total["scratch"]}
+                                  "prefix_loop_valu": res.get("prefix_loop", zero())["valu"], "scratch_instr": total["scratch"] + total["scratch_at_calls"]}
             try:
                 sp = spills(path).get(kernel)
                 if sp:
@@ -190,7 +195,7 @@ def analyse_mul(path=ASM, kernel=K_MUL_CU, nwin=10):
     return {"kernel": kernel, "total": total, "sum_loop": excl[summ], "window_loop": excl[win], "walk_back_loop": excl[back], "windows": nwin,
             "per_scalar_static": est,
             "fingerprint": {"kernel_valu": total["valu"], "window_loop_valu": excl[win]["valu"], "window_loop_mad64": excl[win]["mad64"],
-                            "walk_back_loop_valu": excl[back]["valu"], "scratch_instr": total["scratch"],
+                            "walk_back_loop_valu": excl[back]["valu"], "scratch_instr": total["scratch"] + total["scratch_at_calls"],
                             "window_loop_scratch": excl[win]["scratch"]}}
 
 
@@ -210,7 +215,37 @@ def spills(path=ASM, prefix="_Z5k_add"):
     return out
 
 
+ADD_KERNELS = {"-a c": "_Z5k_addILb1ELb0ELb0EEv8add_args", "-a u": "_Z5k_addILb0ELb1ELb0EEv8add_args", "-a cu": "_Z5k_addILb1ELb1ELb0EEv8add_args",
+               "-a c -endo": "_Z5k_addILb1ELb0ELb1EEv8add_args", "-a u -endo": "_Z5k_addILb0ELb1ELb1EEv8add_args", "-a cu -endo": "_Z5k_addILb1ELb1ELb1EEv8add_args"}
+MUL_KERNELS = {"mul -a c": "_Z11k_mul_checkILb1ELb0EEvPKjjj4wtab8add_argsPjjj", "mul -a u": "_Z11k_mul_checkILb0ELb1EEvPKjjj4wtab8add_argsPjjj",
+               "mul -a cu": K_MUL_CU}
+
+
+def analyse_all(path=ASM):
+    """every shipped instantiation of the two search kernels: fingerprint, registers / spills, and the scratch instructions inside the
+    per-key loops (k_add: prefix-product, table and `which` loops; k_mul_check: window loop) - tests/test_profiles_fresh.py wants 0 there"""
+    sp_add, sp_mul = spills(path), spills(path, "_Z11k_mul_check")
+    out = {}
+    for label, k in ADD_KERNELS.items():
+        a = analyse(path, k)
+        out[label] = {"kernel": k, "fingerprint": a["fingerprint"], "registers": sp_add.get(k),
+                      "scratch_in_loops": {"which": a["which_loop"]["scratch"], "table": a["table_loop"]["scratch"], "prefix": a["prefix_loop"]["scratch"],
+                                           "launch": a["launch_loop"]["scratch"]},
+                      "per_key_static": {x: round(v, 1) for x, v in a["per_key_static"].items()}}
+    for label, k in MUL_KERNELS.items():
+        m = analyse_mul(path, k)
+        out[label] = {"kernel": k, "fingerprint": m["fingerprint"], "registers": sp_mul.get(k),
+                      "scratch_in_loops": {"window": m["window_loop"]["scratch"], "sum": m["sum_loop"]["scratch"], "walk_back": m["walk_back_loop"]["scratch"],
+                                           "sum_at_the_call_of_the_complete_sum": m["sum_loop"]["scratch_at_calls"]},
+                      "per_scalar_static": {x: round(v, 1) for x, v in m["per_scalar_static"].items()}}
+    return out
+
+
 def main():
+    if "--all" in sys.argv:
+        rest = [a for a in sys.argv[1:] if not a.startswith("--")]
+        print(json.dumps(analyse_all(rest[0] if rest else ASM), indent=1))
+        return
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     path = args[0] if args else ASM
     kernel = args[1] if len(args) > 1 else K_ADD33
