@@ -189,9 +189,6 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
                             waves hide the wait states between dependent multiply-adds better than two (profiles/r04_mul_fastsum.txt: 2^26-scalar
                             calls 1391 against 1370 M scalars/s, 2^24 equal); the sum with the scalar in registers needed 67 spills there */
 #endif
-#ifndef ECL_MUL_PARK_WORDS
-#define ECL_MUL_PARK_WORDS 0  /* round-6 A/B: 1 = park canonical 8-word values (256 instead of 288 bytes of parking traffic per scalar; +4 normalisations) */
-#endif
 template <bool A33, bool A65>
 __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __restrict__ k, u32 n, u32 base, const wtab gtab, add_args a,
                                                    u32* __restrict__ tmp, u32 nt, u32 R) {
@@ -223,25 +220,11 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     if (acc.inf) tt = fe_one();
     fe_mul_pair(ys, nprod, acc.Y, acc.ZZ, prod, tt);
     u32* p = tmp + (size_t)r * 36 * nt + t;
-#if ECL_MUL_PARK_WORDS
-    {  // A/B (round 6): the four parked values as canonical 8 x 32-bit words (128 bytes per scalar each way instead of 144)
-      u32 w[4][8];
-      fe_normalize(xs), fe_normalize(ys), fe_normalize(tt);
-      fe pc = prod;
-      fe_normalize(pc);
-      fe_to_words(w[0], xs), fe_to_words(w[1], ys), fe_to_words(w[2], tt), fe_to_words(w[3], pc);
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int l = 0; l < 8; ++l) p[(size_t)(8 * v + l) * nt] = w[v][l];
-    }
-#else
 #pragma unroll
     for (int l = 0; l < FE_LIMBS; ++l) {
       p[(size_t)l * nt] = xs.n[l], p[(size_t)(9 + l) * nt] = ys.n[l];
       p[(size_t)(18 + l) * nt] = tt.n[l], p[(size_t)(27 + l) * nt] = prod.n[l];
     }
-#endif
     prod = nprod;
   }
   fe inv = fe_inv(prod);
@@ -258,22 +241,11 @@ __global__ void __launch_bounds__(256, ECL_MUL_WAVES) k_mul_check(const u32* __r
     const bool have = i < n;
     const u32* p = tmp + (size_t)r * 36 * nt + t;
     fe X, Y, T, pre;
-#if ECL_MUL_PARK_WORDS
-    {
-      u32 w[4][8];
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int l = 0; l < 8; ++l) w[v][l] = have ? p[(size_t)(8 * v + l) * nt] : (v == 2 && l == 0 ? 1u : 0u);
-      X = fe_from_words(w[0]), Y = fe_from_words(w[1]), T = fe_from_words(w[2]), pre = fe_from_words(w[3]);
-    }
-#else
 #pragma unroll
     for (int l = 0; l < FE_LIMBS; ++l) {
       X.n[l] = have ? p[(size_t)l * nt] : 0u, Y.n[l] = have ? p[(size_t)(9 + l) * nt] : 0u;
       T.n[l] = have ? p[(size_t)(18 + l) * nt] : (l == 0 ? 1u : 0u), pre.n[l] = have ? p[(size_t)(27 + l) * nt] : 0u;
     }
-#endif
     fe ti, ninv, x, y;
     fe_mul_pair(ti, ninv, inv, pre, inv, T);  // T = 1 for a lane without a scalar in this round
     inv = ninv;

@@ -59,6 +59,14 @@ def test_bench_secondary_legs_at_reduced_size():
     assert wide["window_bits"] == 29 and wide.get("records_equal_to_the_26_bit_run") and wide["value"] > 100, wide
     assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
     assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
+    assert len(cli["runs_mlines_s"]) == 3 and cli["value"] == sorted(cli["runs_mlines_s"])[1] and cli["pipe"]["value"] > 1 and cli["pipe"]["lines_log2"] == 22
+    # the per-GPU shards of the named range at N = 2, 4, 8 as timed steps of this one GPU, and the efficiency projected from them
+    sh = r["shard_steps"]
+    assert [x["n_gpus"] for x in sh["steps"]] == [2, 4, 8] and [x["keys"] for x in sh["steps"]] == [1 << 31, 1 << 30, 1 << 29]
+    assert all(x["setups"] == 5 and x["kernel_ms_per_step"] < x["ms_per_step"] for x in sh["steps"])  # every step re-positioned the walk
+    for x in sh["steps"]:
+        assert sh["projected_efficiency"][str(x["n_gpus"])] == pytest.approx(sh["full_range_ms_per_step"] / x["n_gpus"] / x["ms_per_step"], abs=1e-3)
+    assert 0.85 < sh["projected_efficiency"]["8"] < 1.05 and "PROJECTION" in sh["label"]
     for leg in (c2, api):  # rooflines priced with the kernels' own PMC profiles when those are in the tree
         if leg["roofline"].get("profile"):
             assert leg["roofline"]["frac"] == pytest.approx(leg["roofline"]["achieved"] / leg["roofline"]["peak"], abs=2e-3)

@@ -5,11 +5,11 @@
 # Counter passes are separate runs with --kernel-trace only (never --pmc together with sys/hip/hsa tracing), one
 # 2^32-key launch each (ECL_HIP_SKIP_SELFTEST=1: no 4096-key self-test launch in the counters).
 # Copy what is to be kept into profiles/ (tracked); bench.py reads profiles/<tag>_roofline.json.
-#   PARTS="ubench headline calib mul cu_endo bench parity" (default: all) selects what is collected; a part that is left out keeps
+#   PARTS="ubench headline calib mul cu_endo bench binding mulcli parity" (default: all) selects what is collected; a part that is left out keeps
 #   whatever profiles/ already holds for it
 set -u
-TAG=${1:-r05}
-PARTS=${PARTS:-ubench headline calib mul cu_endo bench parity}
+TAG=${1:-r06}
+PARTS=${PARTS:-ubench headline calib mul cu_endo bench binding mulcli parity}
 want() { [[ " $PARTS " == *" $1 "* ]]; }
 export TMPDIR=/tmp
 R=$(pwd)
@@ -140,6 +140,15 @@ if want bench; then
   python bench.py > "$O/bench.json" 2> "$O/bench.err"
   cp "$O/bench.json" "profiles/${TAG}_bench.json"
   cat "$O/bench.json"
+fi
+# the reference's own host program bound to the library (unchanged MAX_JOB_SIZE: the look-ahead), and `mul` through the C host program
+if want binding; then
+  python tools/bench_ref_binding.py --tag "$TAG" > "$O/ref_binding.log" 2>&1; echo "bench_ref_binding exit code $?"
+  cp "gpurun_out/${TAG}_ref_binding.txt" "profiles/${TAG}_ref_binding.txt" && cat "profiles/${TAG}_ref_binding.txt"
+fi
+if want mulcli; then
+  bash tools/bench_mul_cli.sh 30 3 > "$O/mul_cli.txt" 2>&1
+  cp "$O/mul_cli.txt" "profiles/${TAG}_mul_cli.txt"; grep -E "^#|run [0-9]|parse only" "profiles/${TAG}_mul_cli.txt" | cut -c1-200
 fi
 # bit-exact found lists against the reference binary on the final build: the whole 2^32-key range of the headline config (54 MB filter)
 # and -a cu -endo over 2^28 keys against the 5.9 GB filter (two runs of tools/full_range_parity.py), both binaries reading the same .blf
