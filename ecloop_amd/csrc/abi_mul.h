@@ -70,14 +70,17 @@ static int build_multable(ecl_hip* h, u32 W, u32** out) {
   hipLaunchKernelGGL(k_mul_g, dim3((nlad + 63) / 64), dim3(64), 0, h->stream, lad_k.p, lad.p, (u8*)nullptr, nlad);
   HIPCHK(h, hipGetLastError());
   // rows: launches of ~2^18 threads (one thread per 16 entries), the parking space of one launch reused by the next
-  const u32 nt = ((tb.stride > tb.top_cnt ? tb.stride : tb.top_cnt) + 15u) / 16u;
+  // (a row wider than 2^20 threads - 25 bits and up - is built in slices of 2^20 threads: 2.4 GB of parking space whatever the width)
+  const u32 nt_row = ((tb.stride > tb.top_cnt ? tb.stride : tb.top_cnt) + 15u) / 16u;
+  const u32 nt = nt_row < (1u << 20) ? nt_row : (1u << 20);
   u32 rows = (1u << 18) / nt;
   rows = rows < 1 ? 1 : (rows > tb.nwin ? tb.nwin : rows);
   HIPCHK(h, hipMalloc(&tmp.p, (size_t)rows * 16 * 36 * nt * sizeof(u32)));
   HIPCHK(h, hipMalloc(&tab.p, wtab_slots(tb) * 16 * sizeof(u32)));
   for (u32 w0 = 0; w0 < tb.nwin; w0 += rows) {
     const u32 ny = tb.nwin - w0 < rows ? tb.nwin - w0 : rows;
-    hipLaunchKernelGGL(k_gtable_rows, dim3((nt + 255) / 256, ny), dim3(256), 0, h->stream, lad.p, tab.p, tmp.p, nt, W, w0);
+    for (u32 t0 = 0; t0 < nt_row; t0 += nt)
+      hipLaunchKernelGGL(k_gtable_rows, dim3((nt + 255) / 256, ny), dim3(256), 0, h->stream, lad.p, tab.p, tmp.p, nt, W, w0, t0);
   }
   HIPCHK(h, hipGetLastError());
   // the check

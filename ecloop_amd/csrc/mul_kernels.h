@@ -115,13 +115,16 @@ __device__ __forceinline__ jac wtab_sum(const u32 kk[9], const wtab t) {
 __device__ __noinline__ jac wtab_sum_complete(const u32 kk[9], const wtab t) { return wtab_sum(kk, t); }
 // rows w0 + blockIdx.y of the table: out[w * per + g] = (g + 1) * P_w for g < count_w, P_w = ladder[w][0]; one thread owns 16
 // consecutive entries (Jacobian, parked in `tmp`, one inversion for the 16 - the scheme of k_init_centres_batched)
+// (a launch covers threads t0 ... t0 + nt of each of its rows: wide rows - 2^24 threads at 29 bits - are built in slices so that the
+// parking space stays at 2.4 GB instead of 38.6)
 __global__ void __launch_bounds__(256) k_gtable_rows(const u32* __restrict__ ladders, u32* __restrict__ table, u32* __restrict__ tmp_all, u32 nt,
-                                                      u32 W, u32 w0) {
+                                                      u32 W, u32 w0, u32 t0) {
   const wtab tb = wtab_make(table, W);
-  const u32 w = w0 + blockIdx.y, t = blockIdx.x * 256u + threadIdx.x;
+  const u32 w = w0 + blockIdx.y, tl = blockIdx.x * 256u + threadIdx.x;  // tl: the thread's place in this launch's parking planes
   const u32 count = wtab_row_count(tb, w);
-  const u32 g0 = t * 16u;
-  if (t >= nt || g0 >= count) return;
+  const u32 g0 = (t0 + tl) * 16u;
+  if (tl >= nt || g0 >= count) return;
+  const u32 t = tl;
   const u32* ladder = ladders + (size_t)w * 32 * 16;
   u32* out = table + (size_t)w * tb.stride * 16;
   u32* tmp = tmp_all + (size_t)blockIdx.y * 16 * 36 * nt;
