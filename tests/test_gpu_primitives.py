@@ -163,6 +163,22 @@ def test_c_abi_error_codes():
         assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 4, None) == -1
         assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 0, C.byref(kept)) == 0 and kept.value == 0
         assert lib.ecl_hip_sort_list(h, hs.ctypes.data, 4, C.byref(kept)) == 0 and kept.value == 1
+        # round 6: record capacities above 2^30 are refused (list mode allocates twice the count: 2^31 and more would wrap 32 bits)
+        big = (1 << 30) + 1
+        assert lib.ecl_hip_add_range(h, start, 2048, out.ctypes.data, big, C.byref(n)) == -1 and lib.ecl_hip_reserve(h, 2048, big) == -1
+        assert lib.ecl_hip_mul_batch(h, start, 1, out.ctypes.data, big, C.byref(n)) == -1 and lib.ecl_hip_reserve_mul(h, 16, big) == -1
+        # ... a reserve call leaves the records of the last call where ecl_hip_fetch_found finds them
+        got = C.c_uint32()
+        assert lib.ecl_hip_add_range(h, start, 4096, out.ctypes.data, 16, C.byref(n)) == -4 and n.value == 4096
+        assert lib.ecl_hip_reserve(h, 4096, 16) == 0 and lib.ecl_hip_reserve_mul(h, 16, 16) == 0
+        rest = np.zeros(4096, dtype=capi.FOUND_DTYPE)
+        assert lib.ecl_hip_fetch_found(h, 16, rest.ctypes.data, 4080, C.byref(got)) == 0 and got.value == 4080
+        assert sorted(int(k) for k in np.concatenate([out["key_offset"], rest["key_offset"][:4080]])) == list(range(4096))
+        # look-ahead switches
+        assert lib.ecl_hip_set_lookahead(h, 1000) == -1 and lib.ecl_hip_set_lookahead(h, 1 << 33) == -1 and lib.ecl_hip_set_lookahead(None, 0) == -1
+        assert lib.ecl_hip_set_lookahead(h, 0) == 0 and lib.ecl_hip_set_lookahead(h, 1 << 26) == 0 and lib.ecl_hip_set_scan_end(h, None) == 0
+        assert lib.ecl_hip_set_scan_end(None, None) == -1 and lib.ecl_hip_get_lookahead_stats(None, None, None, None, None) == -1
+        assert lib.ecl_hip_get_lookahead_stats(h, None, None, None, None) == 0
     finally:
         lib.ecl_hip_close(h)
     lib.ecl_hip_close(None)  # no-op
