@@ -890,6 +890,45 @@ def leg_rnd(args, blf, dense_words, dense_blf, tmp):
                        "found_list_matches_oracle_on_sample": True, "check_s": round(t_check, 1)}}
 
 
+def leg_small_jobs(args, blf, tmp):
+    """The reference's scheduler against the library: `ecloop-hip add` over 2^34 keys handed out in the reference's own jobs of 2^21 keys
+    from the shared counter (ECLOOP_HIP_JOB_KEYS=2097152 = MAX_JOB_SIZE, main.c:16,418-431) - one ecl_hip_add_range call per job, as the
+    reference bound through the ABI makes them (that binary lives under oracle/ and is measured by tools/bench_ref_binding.py,
+    not here).  With the look-ahead (default), without it (the library of round 5), and with eight worker threads on eight contexts of the
+    one GPU; found lines of every run equal to the default large-call run's."""
+    from ecloop_amd.build import build_host_cli
+    cli = build_host_cli()
+    log2 = args.small_jobs_log2
+    rng = "%x:%x" % (RANGE_A, RANGE_A + (1 << log2) - 1)
+
+    def run(env, threads=1):
+        out = os.path.join(tmp, "small_jobs.txt")
+        if os.path.exists(out):
+            os.unlink(out)
+        pr = subprocess.run([cli, "add", "-f", blf, "-r", rng, "-t", str(threads), "-q", "-o", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            stdin=subprocess.DEVNULL, timeout=900, env=dict(os.environ, **env))
+        if pr.returncode != 0:
+            raise SystemExit(f"[bench] small jobs: ecloop-hip add failed: {pr.stderr.decode(errors='replace')[-500:]}")
+        secs, mk, found, checked = _status_of(pr.stderr)
+        if checked != 1 << log2:
+            raise SystemExit(f"[bench] small jobs: checked {checked} of 2^{log2} keys")
+        return mk, secs, sorted(l.rstrip("\n") for l in open(out)) if os.path.exists(out) else []
+
+    job = {"ECLOOP_HIP_JOB_KEYS": str(1 << 21)}
+    base = run({})
+    legs = {"lookahead": run(job), "lookahead_off": run(dict(job, ECL_HIP_LOOKAHEAD_LOG2="0")),
+            "lookahead_8_threads_8_contexts": run(dict(job, ECLOOP_HIP_SHARE_GPU="8"), threads=8)}
+    for k, v in legs.items():
+        if v[2] != base[2]:
+            raise SystemExit(f"[bench] small jobs ({k}): FOUND LIST differs from the large-call run's: {len(v[2])} against {len(base[2])} lines")
+    return {"metric": "Mkeys/sec (add, addr33, handed out in the reference's 2^21-key jobs)", "value": legs["lookahead"][0], "unit": "Mkeys/s",
+            "seconds_by_status_line": legs["lookahead"][1], "lookahead_off": legs["lookahead_off"][0],
+            "eight_worker_threads_on_eight_contexts": legs["lookahead_8_threads_8_contexts"][0], "large_calls": base[0],
+            "config": {"workload": f"ecloop-hip add -r {rng} (2^{log2} keys), 56 MB .blf, -t 1; every ecl_hip_add_range call is one 2^21-key job from the shared "
+                                   "counter (ECLOOP_HIP_JOB_KEYS=2097152); rates by the host program's status line",
+                       "found": len(base[2]), "found_lists_equal_to_the_large_call_run": True}}
+
+
 def leg_mul(args, dev_index, words, blf, tmp, planted):
     """configs[4]: mul -a cu.  (a) 2^24 seeded scalars per call from page-locked host memory through ecl_hip_mul_batch;
     (b) 2^26 64-hex-digit lines through the host program's stdin (the reference's input format)."""
@@ -1072,6 +1111,9 @@ def secondary_legs(args, dev_index):
     t0 = time.perf_counter()
     out["cfg4"] = leg_mul(args, dev_index, words, blf, tmp, planted)
     out["cfg4"]["leg_s"] = round(time.perf_counter() - t0, 1)
+    t0 = time.perf_counter()
+    out["small_jobs"] = leg_small_jobs(args, blf, tmp)
+    out["small_jobs"]["leg_s"] = round(time.perf_counter() - t0, 1)
     out["seconds"] = round(time.perf_counter() - t_all, 1)
     return out
 
@@ -1108,6 +1150,7 @@ def main():
     ap.add_argument("--cfg3-windows", type=int, default=3)
     ap.add_argument("--cfg4-log2", type=int, default=24)
     ap.add_argument("--cfg4-steps", type=int, default=3)
+    ap.add_argument("--small-jobs-log2", type=int, default=34, help="keys of the `small_jobs` leg (the reference's 2^21-key hand-out through the host program)")
     ap.add_argument("--cfg4-cli-log2", type=int, default=0, help="lines fed to the host program; 0 = 2^30 where /dev/shm and RAM allow (70 GB), else 2^28 / 2^26")
     args = ap.parse_args()
     t_process = time.perf_counter()

@@ -37,6 +37,10 @@ static void *scan_worker(void *arg) {
   run_t *run = sn->run;
   u32 cap = 4096;
   ecl_found *buf = malloc(sizeof(ecl_found) * cap);
+  if (!(sn->hashed.w[1] | sn->hashed.w[2] | sn->hashed.w[3])) { /* where the hand-out stops: the library may look ahead over small jobs up to here */
+    sc end = scan_scalar(run, &sn->rs, &sn->hashed);
+    if (sc_cmp(&end, &sn->rs) > 0) ecl_hip_set_scan_end(run->dev[w->g], end.w);
+  }
   for (bool first = true;; first = false) {
     pthread_mutex_lock(&sn->mu);
     sc lo = sn->next, left;
@@ -102,6 +106,12 @@ static void *scan_worker(void *arg) {
    clocks even out, at least 2^27 keys (10 ms of kernel against ~0.4 ms of per-call set-up), at most 2^30. */
 static u64 scan_chunk(const run_t *run, const sc *hashed, bool *fixed) {
   *fixed = false;
+  { /* ECLOOP_HIP_JOB_KEYS=N (measurement): hand the scan out in jobs of N keys from the shared counter whatever its length - with
+       N = 2097152 the reference's own scheduler (MAX_JOB_SIZE, main.c:16,418-431); the library's look-ahead is what keeps the rate */
+    const char *e = getenv("ECLOOP_HIP_JOB_KEYS");
+    const u64 j = e ? strtoull(e, NULL, 0) : 0;
+    if (j >= GROUP_INV_SIZE) return j / GROUP_INV_SIZE * GROUP_INV_SIZE;
+  }
   if (run->ngpus <= 1) return LAUNCH_KEYS;
   if (hashed->w[1] | hashed->w[2] | hashed->w[3]) return 1ull << 30;
   if (hashed->w[0] <= (1ull << 33) && !getenv("ECLOOP_HIP_SHARED_COUNTER")) {

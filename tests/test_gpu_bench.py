@@ -43,7 +43,7 @@ def test_bench_secondary_legs_at_reduced_size():
     minute: every leg present, checked against the oracle on its sample (a mismatch makes bench.py exit non-zero), rates consistent"""
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--cfg2-keys-log2", "27",
                          "--cfg2-steps", "1", "--cfg2-filter-n", "60000000", "--cfg3-windows", "1", "--cfg4-log2", "22", "--cfg4-steps", "2",
-                         "--cfg4-cli-log2", "22"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=ROOT)
+                         "--cfg4-cli-log2", "22", "--small-jobs-log2", "30"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=ROOT)
     assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-3000:]
     r = last_json(pr.stdout)
     assert r["metric"] == "Mkeys/sec (add, addr33)" and r["config"]["keys_per_gpu_per_step"] == 1 << 32  # the headline is untouched
@@ -60,6 +60,9 @@ def test_bench_secondary_legs_at_reduced_size():
     assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
     assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
     assert len(cli["runs_mlines_s"]) == 3 and cli["value"] == sorted(cli["runs_mlines_s"])[1] and cli["pipe"]["value"] > 1 and cli["pipe"]["lines_log2"] == 22
+    # the reference's 2^21-key hand-out through the host program: found lists equal, the look-ahead ahead of plain launches
+    sj = s["small_jobs"]
+    assert sj["config"]["found_lists_equal_to_the_large_call_run"] and sj["value"] > sj["lookahead_off"] > 1000 and sj["eight_worker_threads_on_eight_contexts"] > 1000
     # the per-GPU shards of the named range at N = 2, 4, 8 as timed steps of this one GPU, and the efficiency projected from them
     sh = r["shard_steps"]
     assert [x["n_gpus"] for x in sh["steps"]] == [2, 4, 8] and [x["keys"] for x in sh["steps"]] == [1 << 31, 1 << 30, 1 << 29]
