@@ -164,7 +164,9 @@ static u64 la_room(const ecl_hip* h, const la_group& g, const u256& at) {
 // keys the next sweep should cover when it starts at scalar `at` (a multiple of the job size n; 0: none)
 static u64 la_plan(const ecl_hip* h, const la_group& g, const u256& at, u64 n) {
   u64 lim = h->la_max / n;  // in jobs
-  u64 least = 4;
+  // a sweep has to replace many launches to be worth its latency - and must never turn "one job per GPU" (N equal contiguous shards, one
+  // per context: what a host that knows its GPUs hands out) into one GPU sweeping all of them while the others wait
+  const u64 least = 4ull * (u64)(g.members > 1 ? g.members : 1);
   const u64 room = la_room(h, g, at) / n;
   if (room < lim) lim = room;
   if (h->la_have_end) {
@@ -185,7 +187,6 @@ static u64 la_plan(const ecl_hip* h, const la_group& g, const u256& at, u64 n) {
       const u64 jobs = (e + n - 1) / n;  // the jobs that start before the end (main.c:420: a worker stops at range_s >= range_e)
       if (jobs < lim) lim = jobs;
     }
-    least = 2;
   } else {
     const u64 grown = pow2floor(g.streak_keys / n / 2);
     if (grown < lim) lim = grown;

@@ -201,7 +201,8 @@ int ecl_hip_reserve_mul(ecl_hip *h, uint32_t n, uint32_t cap);
 int ecl_hip_set_lookahead(ecl_hip *h, uint64_t max_keys);
 /* Optional hint: the scalar at which the caller's scan stops handing out jobs (ctx->range_e: a worker stops once range_s >= range_e,
    main.c:420-423); NULL withdraws it.  A sweep then never passes the job that contains `end` - nothing is computed that will not be asked
-   for - and starts with the second contiguous job; without the hint a sweep covers at most half of what the pattern has consumed so far. */
+   for - and starts with the second contiguous job; without the hint a sweep covers at most half of what the pattern has consumed so far.
+   Either way a sweep is only run if it replaces at least 4 jobs per context of the group (N equal shards handed to N GPUs stay N launches). */
 int ecl_hip_set_scan_end(ecl_hip *h, const uint64_t end[4]);
 /* Measurement: sweeps this context has run and their keys; calls answered from a sweep (this context's or a sharing one's) and their keys. */
 int ecl_hip_get_lookahead_stats(ecl_hip *h, uint64_t *sweeps, uint64_t *swept_keys, uint64_t *served_calls, uint64_t *served_keys);

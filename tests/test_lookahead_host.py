@@ -316,3 +316,36 @@ def test_switched_off_by_the_caller_or_by_a_fixed_geometry(L):
         assert L.ecl_hip_set_lookahead(c.h, 1000) == -1 and L.ecl_hip_set_lookahead(c.h, 1 << 33) == -1 and L.ecl_hip_set_lookahead(c.h, 1 << 24) == 0
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("contexts", [2, 8])
+def test_one_shard_per_context_stays_one_launch_per_context(L, contexts):
+    """a host that knows its GPUs hands every context ONE contiguous shard of the scan (the host program's `-t N` on scans up to 2^33 keys):
+    N equal jobs, each starting where the one before ended - the reference's pattern to the letter, but sweeping it would put all shards
+    on one GPU while the others wait.  A sweep must replace at least 4 jobs per context of the group: here every context launches its
+    own shard, in parallel, and nothing is swept."""
+    n, A = 1 << 18, 0x9000_0000
+    ctxs = [Ctx(L, dev=t, one_in=733) for t in range(contexts)]
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            ctxs[t].set_end(A + contexts * n)
+            rc, got, cnt = ctxs[t].add(A + t * n, n)
+            assert rc == 0
+            results[t] = got
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    try:
+        for c in ctxs:  # all contexts are members of the group before the first job arrives
+            c.add(1 << 50, 64)
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(contexts)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors[0]
+        for t in range(contexts):
+            assert same(results[t], ctxs[t].expected(A + t * n, n))
+            assert ctxs[t].stats() == (0, 0, 0, 0) and ctxs[t].device()[:2] == (2, n + 64), (t, ctxs[t].stats(), ctxs[t].device())
+    finally:
+        [c.close() for c in ctxs]
