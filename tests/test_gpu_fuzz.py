@@ -25,3 +25,13 @@ def test_random_mul_batches_equal_the_oracle():
                         stderr=subprocess.STDOUT, timeout=600)
     out = pr.stdout.decode(errors="replace")
     assert pr.returncode == 0 and "ALL EQUAL" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_random_job_sequences_through_the_lookahead_equal_plain_launches():
+    """a short slice of tools/fuzz_lookahead_gpu.py: scans handed out job by job (sizes, strides, selections, filters, sweep limits, worker
+    threads on several contexts, jumps and odd jobs at random) - every call's records equal the same call's on a context without look-ahead"""
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lookahead_gpu.py"), "15", "41"], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, timeout=900)
+    out = pr.stdout.decode(errors="replace")
+    assert pr.returncode == 0 and "ALL EQUAL" in out, out[-2000:]
