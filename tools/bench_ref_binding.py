@@ -78,6 +78,49 @@ def main():
         ok &= same
         rep.append("%-78s: %3d lines %s  wall %5.1f s  status: %s  found set %s" % (binary + ", " + what, len(lines), hashlib.sha256("\n".join(lines).encode()).hexdigest()[:12], dt, status,
                                                                                    "identical" if same else "DIFFERS"))
+    # `mul`: the reference's reader (fgets, 2048-line jobs, main.c:542-576) and workers (hex parse, main.c:503-527) unchanged, each job ONE
+    # ecl_hip_mul_batch call of 2048 scalars: bounded by the reference's own line reader and by the latency of such small calls, stated for
+    # completeness (the library's rate needs calls of 2^20 scalars and more: ecloop-hip's front end, profiles/*_mul_cli.txt)
+    gen = os.path.join(tmp, "gen_hex_lines")
+    subprocess.run(["gcc", "-O2", "-pthread", os.path.join(ROOT, "tools", "gen_hex_lines.c"), "-o", gen], check=True)
+    lines_log2 = 24
+    src = os.path.join(tmp, "mul_in.txt")
+    subprocess.run([gen, str(1 << lines_log2), "7", src, "16"], check=True)
+
+    def run_mul(cmd, env=None):
+        out = os.path.join(tmp, "mul_out.txt")
+        if os.path.exists(out):
+            os.unlink(out)
+        t0 = time.time()
+        pr = subprocess.run(cmd + ["-q", "-o", out], stdin=open(src, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})), timeout=900)
+        dt = time.time() - t0
+        assert pr.returncode == 0, pr.stderr.decode(errors="replace")[-1000:]
+        status = pr.stderr.decode(errors="replace").replace("\x1b[2K", "\r").split("\r")[-1].strip()
+        return sorted(l.rstrip("\n") for l in open(out)) if os.path.exists(out) else [], status, dt
+
+    rep.append("# mul -a cu, 2^%d lines of 64 hex digits from a file on stdin, same .blf (rates by each program's status line)" % lines_log2)
+    mwant, ms, mt = run_mul([cli, "mul", "-f", blf, "-a", "cu"])
+    rep.append("%-78s: %3d lines  wall %5.1f s  status: %s" % ("ecloop-hip mul (batches of 2^24 lines per device call)", len(mwant), mt, ms))
+    for t in (1, 4, 8):
+        path = os.path.join(ref, "ecloop_gpu")
+        if os.path.exists(path):
+            lines, status, dt = run_mul([path, "mul", "-f", blf, "-a", "cu", "-t", str(t)], {"ECLOOP_GPU_CONTEXTS": str(min(t, 8))})
+            # (the reference's tail batch emits stale slots beyond the last line, main.c:467: compare the sets of real keys' lines)
+            same = set(lines) >= set(mwant) and len(set(lines) - set(mwant)) <= 16
+            ok &= same
+            rep.append("%-78s: %3d lines  wall %5.1f s  status: %s  found set %s" % ("ecloop_gpu mul, reference reader + 2048-line jobs, -t %d on %d contexts" % (t, min(t, 8)),
+                                                                                   len(lines), dt, status, "identical" if same else "DIFFERS"))
+    cpu = os.path.join(ref, "ecloop_native")
+    if os.path.exists(cpu):
+        try:
+            small = os.path.join(tmp, "mul_small.txt")
+            open(small, "wb").write(open(src, "rb").read(65 << 21))
+            src_full, src = src, small
+            lines, status, dt = run_mul([cpu, "mul", "-f", blf, "-a", "cu", "-t", "64"])
+            rep.append("%-78s: %3d lines  wall %5.1f s  status: %s" % ("the unmodified reference on the host cores, -t 64, the first 2^21 lines", len(lines), dt, status))
+            src = src_full
+        except Exception as e:  # the native build may not run on this host
+            rep.append("the unmodified reference (ecloop_native) did not run here: %s" % str(e)[:80])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "%s_ref_binding.txt" % a.tag), "w").write("\n".join(rep) + "\n")
     print("\n".join(rep))
