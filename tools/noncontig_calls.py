@@ -12,7 +12,7 @@ from synth import synth_bloom_words
 words = synth_bloom_words(7000003, 23, "a&(b|c)")
 for L in (21, 24):
     n = 1 << L
-    d = capi.Device(0); d.set_bloom(words)
+    d = capi.Device(0); d.set_lookahead(0); d.set_bloom(words)  # (the launches themselves, not the look-ahead)
     start = 0x100000000
     for _ in range(3):
         d.add_range(start, n, cap=4096); start += n + (1 << 40)

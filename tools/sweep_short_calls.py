@@ -23,6 +23,7 @@ for L in sizes:
     calls = max(8, min(400, (1 << 30) >> L))
     for hg in halves:
         d = capi.Device(0)
+        d.set_lookahead(0)  # this tool measures the launches themselves (the geometry model), not the look-ahead over them
         d.set_bloom(words)
         if hg:
             d.set_geometry(hg, 0)
