@@ -262,8 +262,8 @@ static void *raw_pack_worker(void *arg) {
   return NULL;
 }
 
-/* A pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n - task i on worker
-   i mod nth - and returns when all are done.  A 64 MB chunk is ~1 ms of work for 32 threads and they come back to back,
+/* A pool of parse threads that lives as long as the command: run() executes fn(arg[i]) for i < n - each worker takes
+   the next task from a shared counter - and returns when all are done.  A 64 MB chunk is ~1 ms of work for 32 threads and they come back to back,
    so the hand-over must cost microseconds: workers wait for the next generation number spinning (a few hundred
    microseconds at most, then they sleep on a condition variable until woken), finish by bumping one atomic counter.
    (Round 2's pool handed tasks out under a mutex and woke everybody through a condition variable: with 32 threads the
@@ -281,7 +281,7 @@ struct pool_t {
   size_t stride;
   int n;
   atomic_ullong gen;
-  atomic_int done, sleepers;
+  atomic_int done, sleepers, next;
   atomic_bool quit;
   pthread_mutex_t mu;
   pthread_cond_t cv;
@@ -307,7 +307,9 @@ static void *pool_main(void *arg) {
     }
     if (atomic_load(&p->quit)) break;
     seen = atomic_load(&p->gen);
-    for (int i = me->idx; i < p->n; i += p->nth) p->fn(p->args + (size_t)i * p->stride);
+    /* tasks are taken one at a time from a shared counter: a worker that shares its core with something else for a while (the device
+       threads, the runtime's helpers) takes fewer slices instead of holding the whole batch up with a fixed share */
+    for (int i; (i = atomic_fetch_add(&p->next, 1)) < p->n;) p->fn(p->args + (size_t)i * p->stride);
     atomic_fetch_add(&p->done, 1);
   }
   return NULL;
@@ -355,6 +357,7 @@ static void pool_run(pool_t *p, void *(*fn)(void *), void *args, size_t stride, 
   if (n <= 0) return;
   p->fn = fn, p->args = args, p->stride = stride, p->n = n;
   atomic_store(&p->done, 0);
+  atomic_store(&p->next, 0);
   atomic_fetch_add(&p->gen, 1); /* publishes the fields above */
   pool_wake(p);
   for (int spins = 0; atomic_load(&p->done) < p->nth; ++spins) {
