@@ -129,6 +129,32 @@ def test_add_sharded_over_device_threads(cli, tmp_path, ngpu, counter):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3])
+def test_add_handed_out_in_the_references_job_size(cli, tmp_path, threads):
+    """ECLOOP_HIP_JOB_KEYS=2097152: the host program hands its scan out the way the reference's scheduler does - 2^21-key jobs from the
+    shared counter (MAX_JOB_SIZE, main.c:16,418-431), one ecl_hip_add_range call each - with one worker thread and with three on three
+    contexts of the GPU.  The library answers those jobs from look-ahead sweeps (few launches instead of one per job); found lines and
+    status counters equal the default hand-out's, and those of the same run with the look-ahead off, for the reference's golden runs
+    and for a 2^29-key scan through a synthetic filter, `-a cu -endo` included."""
+    flt = str(tmp_path / "f.blf")
+    write_blf(flt, synth_bloom_words(1 << 16, 21, "a|(b&c)"))
+    puz = os.path.join(GOLD, "btc-puzzles-hash")
+    cases = [["-f", puz, "-r", "8000:ffffff"], ["-f", flt, "-r", "100000000:11fffffff"], ["-f", flt, "-r", "100000000:101ffffff", "-a", "cu", "-endo"],
+             ["-f", flt, "-r", "%x:%x" % (1 << 160, (1 << 160) + (((1 << 26) - 1) << 64)), "-d", "64:32"]]
+    for k, args in enumerate(cases):
+        base = run(cli, ["add", "-t", "1"] + args, out=str(tmp_path / ("base%d.txt" % k)))
+        outs = []
+        for e, extra in enumerate(({}, {"ECL_HIP_LOOKAHEAD_LOG2": "0"})):
+            env = dict(os.environ, ECLOOP_HIP_JOB_KEYS=str(1 << 21), ECLOOP_HIP_SHARE_GPU=str(threads), ECLOOP_HIP_STATS="1", **extra)
+            lines, status, stdout = run(cli, ["add", "-t", str(threads)] + args, out=str(tmp_path / ("job%d_%d.txt" % (k, e))), env=env)
+            assert lines == base[0] and counts(status) == counts(base[1]), (k, extra)
+            outs.append(sum(int(m) for m in re.findall(r"^gpu \d+: (\d+) launches", stdout, re.M)))
+        if k == 1:  # 2^29 keys = 256 jobs: a handful of launches with the look-ahead, one per job without
+            assert outs[0] <= 8 + 2 * threads and outs[1] == 256, outs
+        assert len(base[0]) > 0
+
+
+@pytest.mark.gpu
 def test_add_dumps_and_stride(cli, tmp_path):
     ones = str(tmp_path / "ones.blf")
     write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
