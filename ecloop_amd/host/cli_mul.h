@@ -764,7 +764,7 @@ static void cmd_mul(run_t *run) {
   memset(&sq, 0, sizeof sq);
   sq.run = run, sq.narr = run->ngpus + 2;
   pthread_mutex_init(&sq.mu, NULL), pthread_cond_init(&sq.cv, NULL);
-  for (int i = 0; i < sq.narr; ++i) sq.idle[sq.nidle++] = i;
+  for (int i = sq.narr; i-- > 0;) sq.idle[sq.nidle++] = i; /* (taken from the end: array 0 first - the ones allocated during bring-up) */
   for (int i = 0; i < mul_ready_count && i < sq.narr; ++i) sq.arr[i] = mul_ready_arrays[i]; /* allocated during bring-up */
   pthread_t reader, devth[MAX_GPUS];
   mul_dev_arg dargs[MAX_GPUS];
