@@ -515,7 +515,7 @@ static void raw_grow(const run_t *run, scalar_array *ar, size_t text_bytes, size
    page-locking costs 0.3 ms per MB - 45 ms for the four 33 MB arrays of a one-GPU text run, 90 ms with -bin - which the
    first chunks otherwise wait for one after the other. */
 static size_t mul_largest_batch(const run_t *run, u32 *window);
-static size_t mul_batch_records(void);
+static size_t mul_batch_records(size_t total);
 static size_t mul_fixed_file_records(const run_t *run, off_t *pos);
 static scalar_array mul_ready_arrays[MUL_MAX_ARRAYS];
 static int mul_ready_count;
@@ -526,7 +526,7 @@ static void *mul_prealloc(void *arg) {
   const bool raw = a->run->opt.raw && !a->run->bin;
   /* a file of fewer batches than arrays gets only as many as it has batches (page-locking 512 MB takes 0.15 s) */
   off_t pos;
-  const size_t total = mul_fixed_file_records(a->run, &pos), batch = mul_batch_records();
+  const size_t total = mul_fixed_file_records(a->run, &pos), batch = mul_batch_records(total);
   int want = a->narr;
   if (total && (total + batch - 1) / batch < (size_t)want) want = (int)((total + batch - 1) / batch);
   for (int i = 0; i < want && i < MUL_MAX_ARRAYS; ++i) {
@@ -679,10 +679,15 @@ static size_t mul_fixed_file_records(const run_t *run, off_t *pos) {
   if (pread(0, first, MUL_RECORD, *pos) != (ssize_t)MUL_RECORD || first[64] != '\n') return 0;
   return (size_t)(stt.st_size - *pos) / MUL_RECORD;
 }
-static size_t mul_batch_records(void) {
+/* records per batch for a file of `total` records: 2^24 for large files (the device's rate needs calls that long); a smaller file is cut
+   into about eight batches, 2^20 records at least, so that parsing one batch overlaps the device call of the one before and both
+   contexts of the GPU get work (a 2^24-line file as ONE batch: parse 12 ms, then the device 15 ms, nothing overlapped) */
+static size_t mul_batch_records(size_t total) {
   const char *e = getenv("ECLOOP_HIP_MUL_BATCH_LOG2"); /* experiments */
-  const int l = e && atoi(e) >= 10 && atoi(e) <= 26 ? atoi(e) : MUL_BATCH_LOG2;
-  return (size_t)1 << l;
+  if (e && atoi(e) >= 10 && atoi(e) <= 26) return (size_t)1 << atoi(e);
+  size_t b = (size_t)1 << 20;
+  while (b < ((size_t)1 << MUL_BATCH_LOG2) && b * 8 < total) b <<= 1;
+  return b;
 }
 
 /* scalars of the largest array a run will hand to a device (bring-up sizes the device staging and the page-locked arrays by it), and
@@ -692,14 +697,14 @@ static size_t mul_batch_records(void) {
    (22, then 26 after 2^30 scalars: what a pipe gets) */
 static size_t mul_largest_batch(const run_t *run, u32 *window) {
   off_t pos;
-  const size_t total = mul_fixed_file_records(run, &pos), batch = mul_batch_records();
+  const size_t total = mul_fixed_file_records(run, &pos), batch = mul_batch_records(total);
   if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
   if (total) return total < batch ? total : batch;
   return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
 }
 /* the fixed-record path over stdin from `pos`: batches -> arrays -> device threads; returns the records taken */
 static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
-  const size_t batch = mul_batch_records();
+  const size_t batch = mul_batch_records(total);
   const char *how = getenv("ECLOOP_HIP_MUL_READ");
   const char *map = NULL;
   if (how && !strcmp(how, "mmap")) { /* comparison: the mapped form */
