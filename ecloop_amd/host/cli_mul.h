@@ -516,7 +516,7 @@ static void raw_grow(const run_t *run, scalar_array *ar, size_t text_bytes, size
    first chunks otherwise wait for one after the other. */
 static size_t mul_largest_batch(const run_t *run, u32 *window);
 static size_t mul_batch_records(size_t total);
-static size_t mul_fixed_file_records(const run_t *run, off_t *pos);
+static size_t mul_fixed_file_records(const run_t *run, off_t *pos, size_t *rec);
 static scalar_array mul_ready_arrays[MUL_MAX_ARRAYS];
 static int mul_ready_count;
 typedef struct { const run_t *run; int narr; } mul_prealloc_arg;
@@ -526,7 +526,8 @@ static void *mul_prealloc(void *arg) {
   const bool raw = a->run->opt.raw && !a->run->bin;
   /* a file of fewer batches than arrays gets only as many as it has batches (page-locking 512 MB takes 0.15 s) */
   off_t pos;
-  const size_t total = mul_fixed_file_records(a->run, &pos), batch = mul_batch_records(total);
+  size_t rec;
+  const size_t total = mul_fixed_file_records(a->run, &pos, &rec), batch = mul_batch_records(total);
   int want = a->narr;
   if (total && (total + batch - 1) / batch < (size_t)want) want = (int)((total + batch - 1) / batch);
   for (int i = 0; i < want && i < MUL_MAX_ARRAYS; ++i) {
@@ -616,44 +617,56 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
    the input goes through the general reader below, which starts at the file offset this path leaves. */
 #define MUL_BATCH_LOG2 24
 #define MUL_SLICE_RECORDS_MAX 32768u
-typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; atomic_bool bad; } fixed_batch;
+typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; size_t rec; atomic_bool bad; } fixed_batch; /* rec: 65 (LF lines), 66 (CRLF), 32 (-bin) */
 static atomic_ullong fixed_read_us, fixed_decode_us; /* summed over the pool's threads (ECLOOP_HIP_STATS) */
 typedef struct { fixed_batch *b; size_t first, last; } fixed_file_slice;
+static bool pread_all(int fd, char *dst, size_t bytes, off_t at) {
+  for (size_t have = 0; have < bytes;) {
+    ssize_t got = pread(fd, dst + have, bytes - have, at + (off_t)have);
+    if (got <= 0) return false; /* the file shrank under us */
+    have += (size_t)got;
+  }
+  return true;
+}
 static void *fixed_file_worker(void *arg) {
 #if defined(__x86_64__)
   fixed_file_slice *s = arg;
   fixed_batch *b = s->b;
   if (atomic_load(&b->bad)) return NULL;
-  const size_t bytes = (s->last - s->first) * MUL_RECORD;
-  const char *src;
+  const size_t rec = b->rec, bytes = (s->last - s->first) * rec;
+  const off_t at = b->base + (off_t)(s->first * rec);
   const u64 t0 = us_now();
-  if (b->map) src = b->map + b->base + s->first * MUL_RECORD;
+  if (rec == 32) { /* -bin: the scalars as they are, straight into their slots */
+    if (b->map) memcpy(b->dst[s->first], b->map + at, bytes);
+    else if (!pread_all(b->fd, (char *)b->dst[s->first], bytes, at)) atomic_store(&b->bad, true);
+    atomic_fetch_add(&fixed_read_us, us_now() - t0);
+    return NULL;
+  }
+  const char *src;
+  if (b->map) src = b->map + at;
   else {
     static __thread char *mine; /* this thread's text buffer, for the life of the command */
-    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS_MAX * MUL_RECORD))) { atomic_store(&b->bad, true); return NULL; }
-    for (size_t have = 0; have < bytes;) {
-      ssize_t got = pread(b->fd, mine + have, bytes - have, b->base + (off_t)(s->first * MUL_RECORD + have));
-      if (got <= 0) { atomic_store(&b->bad, true); return NULL; } /* the file shrank under us */
-      have += (size_t)got;
-    }
+    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS_MAX * 66))) { atomic_store(&b->bad, true); return NULL; }
+    if (!pread_all(b->fd, mine, bytes, at)) { atomic_store(&b->bad, true); return NULL; }
     src = mine;
   }
-  const bool wide = have_avx2, widest = have_avx512;
+  const bool wide = have_avx2, widest = have_avx512, crlf = rec == 66;
   const u64 t1 = us_now();
   for (size_t r = 0; r < s->last - s->first; ++r) {
-    const char *p = src + r * MUL_RECORD;
+    const char *p = src + r * rec;
     u64 *dst = b->dst[s->first + r];
     sc k;
+    const bool ended = crlf ? p[64] == '\r' && p[65] == '\n' : p[64] == '\n';
     if (widest) { /* one load per record; the scalar goes straight to its slot, reduced there in the one case in 2^128 that needs it */
-      if (p[64] == '\n' && hex64_avx512(p, dst)) {
+      if (ended && hex64_avx512(p, dst)) {
         if (dst[3] == ~0ull) memcpy(k.w, dst, 32), k = sc_reduce(k), memcpy(dst, k.w, 32);
         continue;
       }
       atomic_store(&b->bad, true);
       return NULL;
     }
-    const bool ok = p[64] == '\n' && (wide ? hex32_avx2(p, &k.w[3], &k.w[2]) && hex32_avx2(p + 32, &k.w[1], &k.w[0])
-                                           : hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) && hex16_ssse3(p + 48, &k.w[0]));
+    const bool ok = ended && (wide ? hex32_avx2(p, &k.w[3], &k.w[2]) && hex32_avx2(p + 32, &k.w[1], &k.w[0])
+                                   : hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) && hex16_ssse3(p + 48, &k.w[0]));
     if (!ok) {
       atomic_store(&b->bad, true);
       return NULL;
@@ -667,17 +680,20 @@ static void *fixed_file_worker(void *arg) {
 #endif
   return NULL;
 }
-/* stdin as such a file: the records it holds from the current offset (0: not a regular file, -raw / -bin, no SSSE3, or the first
-   line is not a 64-digit record) */
-static size_t mul_fixed_file_records(const run_t *run, off_t *pos) {
+/* stdin as such a file: the records it holds from the current offset and their length - 65 bytes (64 digits + LF), 66 (+ CR LF), or with
+   -bin 32 (the scalars themselves); 0: not a regular file, -raw, no SSSE3, or the first line is not a 64-digit record */
+static size_t mul_fixed_file_records(const run_t *run, off_t *pos, size_t *rec) {
   struct stat stt;
-  char first[MUL_RECORD];
-  *pos = lseek(0, 0, SEEK_CUR);
+  char first[66];
+  *pos = lseek(0, 0, SEEK_CUR), *rec = MUL_RECORD;
   const char *how = getenv("ECLOOP_HIP_MUL_READ"); /* "chunks": the general reader only (tests compare the two) */
   if (how && !strcmp(how, "chunks")) return 0;
-  if (run->opt.raw || run->bin || !have_ssse3 || *pos < 0 || fstat(0, &stt) != 0 || !S_ISREG(stt.st_mode) || stt.st_size < *pos + (off_t)MUL_RECORD) return 0;
-  if (pread(0, first, MUL_RECORD, *pos) != (ssize_t)MUL_RECORD || first[64] != '\n') return 0;
-  return (size_t)(stt.st_size - *pos) / MUL_RECORD;
+  if (run->opt.raw || *pos < 0 || fstat(0, &stt) != 0 || !S_ISREG(stt.st_mode) || stt.st_size < *pos + 66) return 0;
+  if (run->bin) return *rec = 32, (size_t)(stt.st_size - *pos) / 32;
+  if (!have_ssse3 || pread(0, first, 66, *pos) != 66) return 0;
+  if (first[64] == '\r' && first[65] == '\n') *rec = 66;
+  else if (first[64] != '\n') return 0;
+  return (size_t)(stt.st_size - *pos) / *rec;
 }
 /* records per batch for a file of `total` records: 2^24 for large files (the device's rate needs calls that long); a smaller file is cut
    into about eight batches, 2^20 records at least, so that parsing one batch overlaps the device call of the one before and both
@@ -697,13 +713,15 @@ static size_t mul_batch_records(size_t total) {
    (22, then 26 after 2^30 scalars: what a pipe gets) */
 static size_t mul_largest_batch(const run_t *run, u32 *window) {
   off_t pos;
-  const size_t total = mul_fixed_file_records(run, &pos), batch = mul_batch_records(total);
+  size_t rec;
+  const size_t total = mul_fixed_file_records(run, &pos, &rec), batch = mul_batch_records(total);
   if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
+  (void)rec;
   if (total) return total < batch ? total : batch;
   return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
 }
 /* the fixed-record path over stdin from `pos`: batches -> arrays -> device threads; returns the records taken */
-static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
+static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, size_t rec, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
   const size_t batch = mul_batch_records(total);
   const char *how = getenv("ECLOOP_HIP_MUL_READ");
   const char *map = NULL;
@@ -729,7 +747,7 @@ static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *
     scalar_array *ar = &sq->arr[ai];
     ks_grow(run, ar, nb);
     *t_grow += us_now() - t_mark, t_mark = us_now();
-    fixed_batch b = {0, map, map ? pos + (off_t)(done * MUL_RECORD) : pos + (off_t)(done * MUL_RECORD), ar->ks, false};
+    fixed_batch b = {0, map, pos + (off_t)(done * rec), ar->ks, rec, false};
     int nf = 0;
     for (size_t at = 0; at < nb; at += slice, ++nf) fs[nf] = (fixed_file_slice){&b, at, at + slice < nb ? at + slice : nb};
     pool_run(pool, fixed_file_worker, fs, sizeof fs[0], nf);
@@ -746,7 +764,7 @@ static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *
     pthread_mutex_unlock(&sq->mu);
     done += nb, ++*nbatches;
   }
-  if (lseek(0, pos + (off_t)(done * MUL_RECORD), SEEK_SET) < 0) { fprintf(stderr, "[!] lseek on the input failed\n"); exit(1); }
+  if (lseek(0, pos + (off_t)(done * rec), SEEK_SET) < 0) { fprintf(stderr, "[!] lseek on the input failed\n"); exit(1); }
   return done;
 }
 static void cmd_mul(run_t *run) {
@@ -784,8 +802,9 @@ static void cmd_mul(run_t *run) {
   u64 nbatches = 0, nbatch_records = 0;
   { /* a file of 64-digit lines: whole batches straight from the file; whatever is left (or is not such a file) goes the general way */
     off_t pos;
-    const size_t total = mul_fixed_file_records(run, &pos);
-    if (total) nbatch_records = mul_fixed_file_run(run, &pool, P, &sq, pos, total, &t_array, &t_grow, &t_parse, &nbatches);
+    size_t rec;
+    const size_t total = mul_fixed_file_records(run, &pos, &rec);
+    if (total) nbatch_records = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
   }
   pthread_create(&reader, NULL, mul_reader, &tq);
   for (;;) {

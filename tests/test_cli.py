@@ -615,6 +615,35 @@ def test_mul_parser_file_of_64_digit_lines_in_batches(cli, tmp_path, decoder):
     assert "3 batches of fixed records straight from the file (24576 lines)" in stats
 
 
+def test_mul_parser_crlf_files_and_binary_files_in_batches(cli, tmp_path):
+    """the batch path over a regular file also takes 66-byte records (64 digits + CR LF: key lists written on Windows) and, with -bin,
+    the 32-byte scalars themselves; both against the general reader on the same bytes, a tail that is no whole record included"""
+    import random
+    r = random.Random(10)
+    N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    vals = [r.getrandbits(256) for _ in range(30000)]
+    env = dict(os.environ, ECLOOP_HIP_MUL_BATCH_LOG2="12", ECLOOP_HIP_MUL_SLICE="4096", ECLOOP_HIP_STATS="1")
+
+    def parse(path, *flags, **more):
+        pr = subprocess.run([cli, "parse", *flags], stdin=open(path, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=300, env=dict(env, **more))
+        return pr.stdout.decode().split(), pr.stderr.decode()
+
+    crlf = tmp_path / "crlf.txt"
+    crlf.write_bytes(b"".join(b"%064x\r\n" % v for v in vals) + b"1f\r\n")
+    got, stats = parse(str(crlf))
+    assert got == ["%064x" % (v % N) for v in vals] + ["%064x" % 0x1F] and "8 batches of fixed records straight from the file (30000 lines)" in stats
+    assert parse(str(crlf), ECLOOP_HIP_MUL_READ="chunks")[0] == got
+    mixed = tmp_path / "mixed.txt"  # LF records, then CRLF ones: the path ends where the record length changes
+    mixed.write_bytes(b"".join(b"%064x\n" % v for v in vals[:10000]) + b"".join(b"%064x\r\n" % v for v in vals[10000:]))
+    got, stats = parse(str(mixed))
+    assert got == ["%064x" % (v % N) for v in vals] and "2 batches of fixed records straight from the file (8192 lines)" in stats
+    raw = tmp_path / "k.bin"
+    raw.write_bytes(b"".join(v.to_bytes(32, "little") for v in vals) + b"\x01\x02\x03")
+    got, stats = parse(str(raw), "-bin")
+    assert got == ["%064x" % v for v in vals] and "8 batches of fixed records straight from the file (30000 lines)" in stats
+    assert parse(str(raw), "-bin", ECLOOP_HIP_MUL_READ="chunks")[0] == got and parse(str(raw), "-bin", ECLOOP_HIP_MUL_READ="mmap")[0] == got
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["add"], ["rnd", "-d", "64:64", "-seed", "w"]])
 def test_unbounded_scans_stream_instead_of_being_refused(cli, tmp_path, args):
