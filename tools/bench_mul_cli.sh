@@ -31,6 +31,23 @@ run "file  (mmap form, round 5)      " file ECLOOP_HIP_MUL_READ=mmap
 run "file  (general reader, 64 MB)   " file ECLOOP_HIP_MUL_READ=chunks
 run "file  (AVX2 decoder)            " file ECLOOP_HIP_NO_AVX512=1
 for T in 8 24 32; do run "file  (pread, $T parse threads)  " file ECLOOP_HIP_PARSE_THREADS=$T; done
+# the same scalars as 32-byte little-endian records (`-bin`, not in the reference: for feeders that can produce more than text parsing takes)
+python3 - $DIR/mul_in.txt $DIR/mul_in.bin <<'PY'
+import os
+import sys
+import numpy as np
+src, dst = sys.argv[1], sys.argv[2]
+n = min(1 << 28, os.path.getsize(src) // 65)
+t = np.fromfile(src, dtype=np.uint8, count=n * 65).reshape(n, 65)[:, :64]
+v = np.where(t >= 97, t - 87, t - 48).astype(np.uint8)
+b = (v[:, 0::2] << 4 | v[:, 1::2])[:, ::-1]   # big-endian digits -> little-endian limbs
+np.ascontiguousarray(b).tofile(dst)
+PY
+for rep in $(seq 1 $REPS); do
+  t0=$(date +%s.%N); env ECLOOP_HIP_STATS=1 "$CLI" mul -f "$ROOT/tests/golden/btc-bw-hash" -a cu -bin -q -o /tmp/mul_out.txt < $DIR/mul_in.bin 2>/tmp/mul_err.txt >/dev/null; t1=$(date +%s.%N)
+  echo "file  (-bin, the first 2^28 scalars) run $rep: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s | status line: $(tr '\r' '\n' < /tmp/mul_err.txt | grep Mkeys | tail -1)"
+done
+rm -f $DIR/mul_in.bin
 echo "# the front end alone (hidden command \`parse\`, nothing printed, no GPU):"
 for T in 8 16 32; do
   for m in pread mmap; do
