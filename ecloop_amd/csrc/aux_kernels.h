@@ -172,6 +172,71 @@ __global__ void k_list_compact(const u32* __restrict__ in, const u32* __restrict
   for (int k = 0; k < 5; ++k) out[(size_t)pos[i] * 5 + k] = in[(size_t)i * 5 + k];
 }
 
+// ---- the sort and the scan of the list preparation, written out (rounds 3-5 called hipCUB for them) ---------------------------------
+// A stable LSD radix sort of (key, index) pairs, 8 bits per pass: `nt` threads own consecutive tiles of the input (thread t: elements
+// [t L, (t + 1) L)); pass = count the digits of the tile into the thread's column of an LDS table, exclusive scan of all counts in
+// digit-major / thread-minor order (= the position of each thread's first element of each digit), then every thread walks its tile
+// again IN ORDER and puts each pair at its digit's running position.  Tiles are in index order and a thread keeps the order inside its
+// tile, so equal digits keep their order: the five word passes of load_filter's qsort order (compare_160, addr.c:18-26) need that.
+// One wave per workgroup (64 x 256 counters of 4 bytes = 64 KB of LDS: two workgroups per CU); a list is prepared once per run, 10^7
+// entries take tens of milliseconds - nothing here is on the hot path.
+#define RSORT_BLOCK 64u
+__global__ void __launch_bounds__(RSORT_BLOCK) k_rsort_count(const u32* __restrict__ key, u32 n, u32 nt, u32 L, u32 shift, u32* __restrict__ counts) {
+  __shared__ u32 cnt[256][RSORT_BLOCK];
+  const u32 t = blockIdx.x * RSORT_BLOCK + threadIdx.x;
+  for (u32 d = 0; d < 256; ++d) cnt[d][threadIdx.x] = 0;
+  if (t < nt) {
+    const u64 lo = (u64)t * L, hi = lo + L < n ? lo + L : n;
+    for (u64 i = lo; i < hi; ++i) cnt[(key[i] >> shift) & 255u][threadIdx.x] += 1;
+    for (u32 d = 0; d < 256; ++d) counts[(size_t)d * nt + t] = cnt[d][threadIdx.x];
+  }
+}
+__global__ void __launch_bounds__(RSORT_BLOCK) k_rsort_scatter(const u32* __restrict__ key, const u32* __restrict__ val, u32 n, u32 nt, u32 L, u32 shift,
+                                                               const u32* __restrict__ offs, u32* __restrict__ key_out, u32* __restrict__ val_out) {
+  __shared__ u32 at[256][RSORT_BLOCK];
+  const u32 t = blockIdx.x * RSORT_BLOCK + threadIdx.x;
+  if (t >= nt) return;
+  for (u32 d = 0; d < 256; ++d) at[d][threadIdx.x] = offs[(size_t)d * nt + t];
+  const u64 lo = (u64)t * L, hi = lo + L < n ? lo + L : n;
+  for (u64 i = lo; i < hi; ++i) {
+    const u32 k = key[i], pos = at[(k >> shift) & 255u][threadIdx.x]++;
+    key_out[pos] = k, val_out[pos] = val[i];
+  }
+}
+// exclusive prefix sums of n 32-bit counts (totals below 2^32): a workgroup scans 2048 elements (8 per thread, Hillis-Steele over the
+// threads' sums in LDS) and leaves its total in `sums`; the totals are scanned the same way one level up, and added back
+#define SCAN_BLOCK 256u
+#define SCAN_PER 8u
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const u32* __restrict__ in, u32* __restrict__ out, u64 n, u32* __restrict__ sums) {
+  __shared__ u32 part[SCAN_BLOCK];
+  const u64 base = ((u64)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_PER;
+  u32 v[SCAN_PER], mine = 0;
+#pragma unroll
+  for (u32 k = 0; k < SCAN_PER; ++k) v[k] = base + k < n ? in[base + k] : 0u, mine += v[k];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (u32 step = 1; step < SCAN_BLOCK; step <<= 1) {
+    const u32 add = threadIdx.x >= step ? part[threadIdx.x - step] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - mine;  // exclusive prefix of this thread inside the workgroup
+#pragma unroll
+  for (u32 k = 0; k < SCAN_PER; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == SCAN_BLOCK - 1 && sums) sums[blockIdx.x] = part[SCAN_BLOCK - 1];
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(u32* __restrict__ out, u64 n, const u32* __restrict__ sums_scanned) {
+  const u64 base = ((u64)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_PER;
+  const u32 add = sums_scanned[blockIdx.x];
+#pragma unroll
+  for (u32 k = 0; k < SCAN_PER; ++k)
+    if (base + k < n) out[base + k] += add;
+}
+
 // ctx_check_hash's second step (main.c:212-216) for the records a search kernel left in `in`: bsearch over the sorted
 // list (order of compare_160, addr.c:18-26: lexicographic on the five words); members are compacted into `out`.
 // Its own tiny kernel after the search kernel, so the hot loop carries nothing for it (in the loop it cost 0.5 %).

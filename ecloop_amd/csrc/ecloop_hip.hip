@@ -3,7 +3,6 @@
 #include "../../include/ecloop_hip.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -247,11 +246,45 @@ int ecl_hip_set_list(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) {
 
 // ---- load_filter's list preparation (main.c:96-131: qsort by compare_160, then one blf_add per entry) on the device ------
 // 10^7 entries cost the host 13 s (qsort of 20-byte records + 2 * 10^8 scattered bit sets), 10^8 two minutes; here: five
-// stable 32-bit radix passes over a permutation (least significant word first = compare_160's word-by-word order,
-// addr.c:18-26), a gather, adjacent-duplicate flags + exclusive scan + scatter.  The bits are set by the bulk insert
-// kernel into a filter of the reference's list-mode size (2 words per entry).
+// stable 32-bit radix sorts of a permutation (least significant word first = compare_160's word-by-word order,
+// addr.c:18-26; each four 8-bit passes: aux_kernels.h), a gather, adjacent-duplicate flags + exclusive scan + scatter.  The bits are
+// set by the bulk insert kernel into a filter of the reference's list-mode size (2 words per entry).
 }  // extern "C"
-// (the kernels: aux_kernels.h)
+// exclusive scan of n counts on the handle's stream; `tmp` holds the two upper levels (n / 2048 + n / 2048^2 + 2 words)
+static u64 scan_tmp_words(u64 n) {
+  const u64 per = (u64)SCAN_BLOCK * SCAN_PER, l1 = (n + per - 1) / per, l2 = (l1 + per - 1) / per;
+  return l1 + l2 + 2;
+}
+static int scan_exclusive(ecl_hip* h, const u32* in, u32* out, u64 n, u32* tmp) {
+  const u64 per = (u64)SCAN_BLOCK * SCAN_PER, nb = (n + per - 1) / per;
+  if (nb <= 1) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, (u32*)nullptr);
+    HIPCHK(h, hipGetLastError());
+    return ECL_OK;
+  }
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, tmp);
+  HIPCHK(h, hipGetLastError());
+  const int rc = scan_exclusive(h, tmp, tmp, nb, tmp + nb);  // the workgroups' totals, in place, one level up
+  if (rc != ECL_OK) return rc;
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, h->stream, out, n, tmp);
+  HIPCHK(h, hipGetLastError());
+  return ECL_OK;
+}
+// stable sort of the n (key, value) pairs by key: four 8-bit passes, result back in key[0] / val[0]
+static int rsort_pairs(ecl_hip* h, u32* key[2], u32* val[2], u32 n, u32 nt, u32 L, u32* counts, u32* scan_tmp) {
+  const dim3 grid((nt + RSORT_BLOCK - 1) / RSORT_BLOCK), blk(RSORT_BLOCK);
+  int cur = 0;
+  for (u32 shift = 0; shift < 32; shift += 8) {
+    hipLaunchKernelGGL(k_rsort_count, grid, blk, 0, h->stream, key[cur], n, nt, L, shift, counts);
+    HIPCHK(h, hipGetLastError());
+    const int rc = scan_exclusive(h, counts, counts, (u64)256 * nt, scan_tmp);
+    if (rc != ECL_OK) return rc;
+    hipLaunchKernelGGL(k_rsort_scatter, grid, blk, 0, h->stream, key[cur], val[cur], n, nt, L, shift, counts, key[cur ^ 1], val[cur ^ 1]);
+    HIPCHK(h, hipGetLastError());
+    cur ^= 1;
+  }
+  return ECL_OK;  // four passes: an even number of swaps
+}
 extern "C" {
 int ecl_hip_sort_list(ecl_hip* h, uint32_t (*h160)[5], uint64_t n, uint64_t* kept) {
   if (!h || !kept || (n && !h160) || n >= (1ull << 31)) return ECL_E_ARG;
@@ -259,8 +292,11 @@ int ecl_hip_sort_list(ecl_hip* h, uint32_t (*h160)[5], uint64_t n, uint64_t* kep
   if (n == 0) return ECL_OK;
   HIPCHK(h, hipSetDevice(h->dev));
   const u32 N = (u32)n;
-  dbuf<u32> rec, out, key[2], perm[2], flag, pos;
-  dbuf<u8> tmp;
+  // threads of the sort: tiles of at least 256 elements, at most 65536 threads
+  u32 nt = (N + 255u) / 256u;
+  nt = nt < RSORT_BLOCK ? RSORT_BLOCK : nt > 65536u ? 65536u : nt;
+  const u32 L = (N + nt - 1) / nt;
+  dbuf<u32> rec, out, key[2], perm[2], flag, pos, counts, tmp;
   HIPCHK(h, hipMalloc(&rec.p, (size_t)N * 20));
   HIPCHK(h, hipMalloc(&out.p, (size_t)N * 20));
   for (int i = 0; i < 2; ++i) {
@@ -269,22 +305,26 @@ int ecl_hip_sort_list(ecl_hip* h, uint32_t (*h160)[5], uint64_t n, uint64_t* kep
   }
   HIPCHK(h, hipMalloc(&flag.p, (size_t)N * 4));
   HIPCHK(h, hipMalloc(&pos.p, (size_t)N * 4));
-  size_t need_sort = 0, need_scan = 0;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, key[0].p, key[1].p, perm[0].p, perm[1].p, (int)N, 0, 32, h->stream));
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, flag.p, pos.p, (int)N, h->stream));
-  size_t need = need_sort > need_scan ? need_sort : need_scan;
-  HIPCHK(h, hipMalloc(&tmp.p, need ? need : 16));
+  HIPCHK(h, hipMalloc(&counts.p, (size_t)256 * nt * 4));
+  const u64 tmp_words = scan_tmp_words((u64)256 * nt) > scan_tmp_words(N) ? scan_tmp_words((u64)256 * nt) : scan_tmp_words(N);
+  HIPCHK(h, hipMalloc(&tmp.p, (size_t)tmp_words * 4));
   HIPCHK(h, hipMemcpyAsync(rec.p, h160, (size_t)N * 20, hipMemcpyHostToDevice, h->stream));
   const dim3 grid((N + 255) / 256), blk(256);
   hipLaunchKernelGGL(k_list_iota, grid, blk, 0, h->stream, perm[0].p, N);
-  int cur = 0;
-  for (int word = 4; word >= 0; --word) {  // LSD: the last word first, every pass stable
-    hipLaunchKernelGGL(k_list_key, grid, blk, 0, h->stream, rec.p, perm[cur].p, key[0].p, N, (u32)word);
-    HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(tmp.p, need, key[0].p, key[1].p, perm[cur].p, perm[cur ^ 1].p, (int)N, 0, 32, h->stream));
-    cur ^= 1;
+  u32* kk[2] = {key[0].p, key[1].p};
+  u32* pp[2] = {perm[0].p, perm[1].p};
+  for (int word = 4; word >= 0; --word) {  // LSD: the last word first, every sort stable
+    hipLaunchKernelGGL(k_list_key, grid, blk, 0, h->stream, rec.p, pp[0], kk[0], N, (u32)word);
+    HIPCHK(h, hipGetLastError());
+    const int rc = rsort_pairs(h, kk, pp, N, nt, L, counts.p, tmp.p);
+    if (rc != ECL_OK) return rc;
   }
-  hipLaunchKernelGGL(k_list_gather_flag, grid, blk, 0, h->stream, rec.p, perm[cur].p, out.p, flag.p, N);
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(tmp.p, need, flag.p, pos.p, (int)N, h->stream));
+  hipLaunchKernelGGL(k_list_gather_flag, grid, blk, 0, h->stream, rec.p, pp[0], out.p, flag.p, N);
+  HIPCHK(h, hipGetLastError());
+  {
+    const int rc = scan_exclusive(h, flag.p, pos.p, N, tmp.p);
+    if (rc != ECL_OK) return rc;
+  }
   hipLaunchKernelGGL(k_list_compact, grid, blk, 0, h->stream, out.p, flag.p, pos.p, rec.p, N);
   HIPCHK(h, hipGetLastError());
   u32 last_pos = 0, last_flag = 0;

@@ -157,9 +157,9 @@ int ecl_hip_mul_batch_raw(ecl_hip *h, const uint8_t *text, uint32_t text_bytes, 
 
 /* load_filter's list preparation (main.c:112-124: qsort by compare_160, then duplicates removed - the same here) on the device:
    sorts the n entries of h160 in place into compare_160 order (addr.c:18-26: word by word), removes duplicates, *kept =
-   entries left at the front of the array.  (The radix passes and the scan are hipCUB calls - library code, off the hot
-   path: a list is prepared once per run.)  n < 2^31.  10^7 entries: 13 s of qsort + bit setting on the host, well under a
-   second here (the bits: ecl_hip_set_bloom of a zero filter + ecl_hip_bloom_insert + ecl_hip_get_bloom). */
+   entries left at the front of the array.  (Five stable 32-bit radix sorts of an index permutation, least significant word first,
+   then adjacent-duplicate flags, a scan and a scatter: this library's own kernels, off the hot path - a list is prepared once per
+   run.)  n < 2^31.  10^7 entries: 13 s of qsort + bit setting on the host, 0.05 s here (the bits: ecl_hip_set_bloom of a zero filter + ecl_hip_bloom_insert + ecl_hip_get_bloom). */
 int ecl_hip_sort_list(ecl_hip *h, uint32_t (*h160)[5], uint64_t n, uint64_t *kept);
 
 /* blf_add (utils.c:290-306) in bulk: set the 20 bits of each of n hash160 values (h160_t words) in the resident

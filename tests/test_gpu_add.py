@@ -689,6 +689,30 @@ def test_sort_list_on_the_device_equals_qsort_by_compare_160():
         d.close()
 
 
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 255, 257, 16384, 16385, 1_000_003, 17_000_001])
+def test_sort_list_sizes_around_the_sorts_tiles_and_scan_levels(n):
+    """the hand-written radix sort + scan behind ecl_hip_sort_list (aux_kernels.h) at sizes around its structure: fewer elements than
+    threads, one more than a whole number of 256-element tiles, the switch to 65536 threads with longer tiles (17 M), two and three scan
+    levels; keys with few distinct values per word (long runs of equal digits: stability) mixed with random ones; against numpy's lexsort"""
+    from ecloop_amd import Device
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 1 << 32, (n, 5), dtype=np.uint64).astype(np.uint32)
+    a[: n // 2, 0] = rng.integers(0, 3, n // 2)          # the most significant word nearly constant in one half
+    a[n // 3 : 2 * n // 3, 4] &= np.uint32(0xFF00)      # low word with two zero bytes
+    if n > 1000:
+        a[n // 5 : n // 5 + n // 10] = a[: n // 10]      # a tenth of the list duplicated
+    d = Device(0)
+    try:
+        got = d.sort_list(a)
+    finally:
+        d.close()
+    order = np.lexsort(tuple(a[:, k] for k in (4, 3, 2, 1, 0)))
+    s_ = a[order]
+    keep = np.ones(n, dtype=bool)
+    keep[1:] = (s_[1:] != s_[:-1]).any(axis=1)
+    assert np.array_equal(got, s_[keep])
+
+
 def test_mul_batch_raw_first_call_of_many_fresh_contexts():
     """the first raw call of a context allocates and clears its text buffer; the clearing once ran on the legacy stream and
     could land on text already copied (lines hashed wrong, now and then).  Forty fresh contexts, a text of several MB each,
