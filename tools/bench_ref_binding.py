@@ -100,7 +100,7 @@ def main():
 
     rep.append("# mul -a cu, 2^%d lines of 64 hex digits from a file on stdin, same .blf (rates by each program's status line)" % lines_log2)
     mwant, ms, mt = run_mul([cli, "mul", "-f", blf, "-a", "cu"])
-    rep.append("%-78s: %3d lines  wall %5.1f s  status: %s" % ("ecloop-hip mul (batches of 2^24 lines per device call)", len(mwant), mt, ms))
+    rep.append("%-78s: %3d lines  wall %5.1f s  status: %s" % ("ecloop-hip mul (batches of records straight from the file)", len(mwant), mt, ms))
     for t in (1, 4, 8):
         path = os.path.join(ref, "ecloop_gpu")
         if os.path.exists(path):
