@@ -312,7 +312,10 @@ static int la_add_range(ecl_hip* h, const u256& k0, u64 n, ecl_found* out, u32 c
     if (r) {  // inside a sweep that is still running
       bool mine_busy = false;
       for (auto& c : g.regions) mine_busy |= !c->ready && c->dev == h->dev;
-      const u64 L = (!mine_busy && !g.blocked && g.pat && n == g.job_n && la_may_sweep(h, g)) ? la_plan(h, g, g.next, n) : 0;
+      // (... as long as the group does not already hold a sweep per context and one more: a device that runs far ahead of the others would
+      // only push stretches nobody has come for yet out of the list)
+      const bool crowded = g.regions.size() > (size_t)(g.members > 1 ? g.members : 1);
+      const u64 L = (!mine_busy && !crowded && !g.blocked && g.pat && n == g.job_n && la_may_sweep(h, g)) ? la_plan(h, g, g.next, n) : 0;
       if (L) {
         const u256 at = g.next;
         (void)la_claim_and_sweep(h, g, lk, at, L);
