@@ -22,7 +22,7 @@
 // reaches 2^30-key sweeps after 2^31 keys.
 //
 // Several contexts (the reference's -t N: one worker thread per context, all pulling from the same counter).  Contexts opened with the
-// same flags and stride whose filters have the same fingerprint form a group; sweeps, pattern and records belong to the group, guarded
+// same flags and stride whose filters have the same fingerprint (over all of their words, computed on the device) form a group; sweeps, pattern and records belong to the group, guarded
 // by its mutex.  A job handed to one context is answered from a sweep another context ran; a context whose job lies in a sweep that is
 // still running on ANOTHER device first claims the next stretch for its own GPU, so N GPUs run N consecutive sweeps at once (contexts
 // on the same device wait instead: a second sweep there would only share the chip).
@@ -82,23 +82,7 @@ static u64 la_default_max() {
   return 1ull << l;
 }
 
-// fingerprint of what a filter holds: enough words to tell different filters apart, cheap for a 6 GB one
-static u64 la_fp_words(const void* p, u64 nbytes) {
-  const u64 n = nbytes / 8;
-  const u64* w = (const u64*)p;
-  u64 hsh = 0xcbf29ce484222325ull ^ nbytes;
-  const u64 samples = n < 65536 ? n : 65536, step = samples ? n / samples : 1;
-  for (u64 i = 0; i < samples; ++i) hsh = (hsh ^ w[i * step]) * 0x100000001b3ull, hsh ^= hsh >> 29;
-  if (n) hsh = (hsh ^ w[n - 1]) * 0x100000001b3ull;
-  const unsigned char* tail = (const unsigned char*)p + n * 8;
-  for (u64 i = 0; i < nbytes % 8; ++i) hsh = (hsh ^ tail[i]) * 0x100000001b3ull;
-  return hsh;
-}
-static void la_filter_changed(ecl_hip* h, const uint64_t* bits, uint64_t nwords) {
-  h->la_bloom_fp = la_fp_words(bits, nwords * 8), h->la_key_valid = true;
-}
-static void la_list_changed(ecl_hip* h, const uint32_t (*h160)[5], uint64_t n) { h->la_list_fp = n ? la_fp_words(h160, n * 20) : 0; }
-
+// (the fingerprints of a context's filter and list - la_bloom_fp, la_list_fp - are computed where the words are resident: ecloop_hip.hip)
 static void la_leave(ecl_hip* h) {
   if (!h->grp) return;
   {

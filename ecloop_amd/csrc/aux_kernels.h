@@ -172,6 +172,21 @@ __global__ void k_list_compact(const u32* __restrict__ in, const u32* __restrict
   for (int k = 0; k < 5; ++k) out[(size_t)pos[i] * 5 + k] = in[(size_t)i * 5 + k];
 }
 
+// fingerprint of n 64-bit words resident on the device (the look-ahead groups contexts by what their filters HOLD, abi_lookahead.h): the
+// sum over all words of mix(word + index * odd constant) - order-free, so the grid adds it up with one atomic per wave; any differing word
+// changes it but for a 2^-64 accident
+__global__ void __launch_bounds__(256) k_fingerprint(const u64* __restrict__ w, u64 n, unsigned long long* __restrict__ out) {
+  u64 acc = 0;
+  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) {
+    u64 z = w[i] + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    acc += z ^ (z >> 31);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down((unsigned long long)acc, off, 64);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+
 // ---- the sort and the scan of the list preparation, written out (rounds 3-5 called hipCUB for them) ---------------------------------
 // A stable LSD radix sort of (key, index) pairs, 8 bits per pass: `nt` threads own consecutive tiles of the input (thread t: elements
 // [t L, (t + 1) L)); pass = count the digits of the tile into the thread's column of an LDS table, exclusive scan of all counts in

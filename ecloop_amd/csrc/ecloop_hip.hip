@@ -741,6 +741,33 @@ static int add_core(ecl_hip* h, const u256& k0, uint64_t nkeys, ecl_found* out, 
 
 #include "abi_lookahead.h"
 
+// fingerprint of what a filter / a list holds, computed over ALL of its words where they are resident (k_fingerprint, aux_kernels.h: a 6 GB
+// filter takes 2 ms): contexts share sweeps only if flags, stride, sizes and these agree.  A failure here only switches the look-ahead off.
+static bool la_device_fingerprint(ecl_hip* h, const void* d_words, u64 nwords64, u64* fp) {
+  dbuf<unsigned long long> acc;
+  if (hipMalloc(&acc.p, 8) != hipSuccess || hipMemsetAsync(acc.p, 0, 8, h->stream) != hipSuccess) return false;
+  const u64 blocks = (nwords64 + 255) / 256;
+  hipLaunchKernelGGL(k_fingerprint, dim3((unsigned)(blocks < 16384 ? (blocks ? blocks : 1) : 16384)), dim3(256), 0, h->stream, (const u64*)d_words, nwords64, acc.p);
+  unsigned long long v = 0;
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&v, acc.p, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return false;
+  *fp = v;
+  return true;
+}
+static void la_filter_changed(ecl_hip* h, const uint64_t*, uint64_t nwords) { h->la_key_valid = la_device_fingerprint(h, h->d_bloom, nwords, &h->la_bloom_fp); }
+static void la_list_changed(ecl_hip* h, const uint32_t (*list)[5], uint64_t n) {
+  h->la_list_fp = 0;
+  if (!n) return;
+  // the list's 20-byte entries as 64-bit words (n * 5 / 2, a last odd 32-bit word left to the entry count in the key: lists are sorted and
+  // unique, so two lists that agree in everything but that word differ in it alone - it is added from the host copy)
+  u64 fp = 0;
+  if (!la_device_fingerprint(h, h->d_list, n * 5 / 2, &fp)) h->la_key_valid = false;
+  if ((n * 5) & 1) fp += 0x9E3779B97F4A7C15ull * ((u64)list[n - 1][4] + 1);
+  h->la_list_fp = fp;
+}
+
+
 extern "C" int ecl_hip_add_range(ecl_hip* h, const uint64_t start[4], uint64_t nkeys, ecl_found* out, uint32_t cap,
                                  uint32_t* nout) {
   if (!h || !start || (!out && cap) || !nout || cap > ECL_CAP_MAX) return ECL_E_ARG;

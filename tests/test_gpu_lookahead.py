@@ -197,19 +197,34 @@ def test_worker_threads_on_several_contexts_share_the_sweeps(contexts):
 
 
 def test_contexts_with_different_filters_do_not_share():
-    """two contexts whose filters differ in one word walk the same jobs alternately: each must see its own filter's hits (groups are keyed
-    by a fingerprint of the filter words, the flags and the stride)"""
+    """contexts whose filters differ walk the same jobs alternately: each must see its own filter's hits and run its own sweeps (groups are
+    keyed by a fingerprint over ALL filter words as they are resident on the device, the flags and the stride) - a filter with every other
+    word changed, and one that differs from the first in a single bit"""
     w1 = synth_bloom_words(1 << 16, 12, "a|(b&c)")
     w2 = w1.copy()
     w2[::2] |= np.uint64(0x00FF00FF00FF00FF)
+    w3 = w1.copy()
+    w3[33333] ^= np.uint64(1 << 17)
     A = 0x9_0000_0000
-    p1, p2, a1, a2 = plain_device(w1), plain_device(w2), ahead_device(w1), ahead_device(w2)
+    p1, p2, p3, a1, a2, a3 = plain_device(w1), plain_device(w2), plain_device(w3), ahead_device(w1), ahead_device(w2), ahead_device(w3)
     try:
         for j in range(12):
-            for p, a in ((p1, a1), (p2, a2)):
+            for p, a in ((p1, a1), (p2, a2), (p3, a3)):
                 want, nw = p.add_range(A + j * JOB, JOB, cap=1 << 14)
                 got, ng = a.add_range(A + j * JOB, JOB, cap=1 << 14)
                 assert ng == nw and key(got) == key(want), j
-        assert a1.lookahead_stats()[0] >= 1 and a2.lookahead_stats()[0] >= 1
+        # every context swept for itself (a shared group would have answered the later contexts from the first one's sweeps)
+        assert all(a.lookahead_stats()[0] >= 1 and a.lookahead_stats()[2] >= 4 for a in (a1, a2, a3))
+        # ... while a fourth context with the first one's filter - uploaded from another host copy - does join its group
+        a4 = ahead_device(w1.copy())
+        try:
+            a1.set_scan_end(A + 64 * JOB), a4.set_scan_end(A + 64 * JOB)
+            for j in range(12, 40):
+                got, ng = (a1 if j % 2 else a4).add_range(A + j * JOB, JOB, cap=1 << 14)
+                want, nw = p1.add_range(A + j * JOB, JOB, cap=1 << 14)
+                assert ng == nw and key(got) == key(want), j
+            assert a4.lookahead_stats()[2] >= 10 and a4.lookahead_stats()[0] + a1.lookahead_stats()[0] <= 4
+        finally:
+            a4.close()
     finally:
-        [d.close() for d in (p1, p2, a1, a2)]
+        [d.close() for d in (p1, p2, p3, a1, a2, a3)]
