@@ -1,9 +1,24 @@
 /* cli_rnd_blf.h - `rnd` (window generator), `blf-gen` / `blf-check`, range and window arguments, usage.
    Part of the one translation unit ecloop_hip_cli.c (included there, in this order). */
 /* ------------------------------------------------------------------------------------------- rnd */
-/* 64 random bits: /dev/urandom, or - with -seed - pairs of rand() (utils.c:83-113) */
+/* 64 random bits: /dev/urandom, or - with -seed - pairs of rand() (utils.c:83-113).  The seeded stream is glibc's rand() after
+   srand(encode_seed(seed)) (main.c:800-805, utils.c:105-113) drawn from a generator state of this program's own (random_r): rand()'s
+   state is process-wide, and the GPU runtime's threads draw from it too - with it a seeded run gave other windows every time
+   (round 6: found when two runs with one seed were compared) */
+static struct random_data seeded_state;
+static char seeded_buf[128];
+static void seeded_start(const char *seed) {
+  u32 hsh = 0; /* encode_seed, utils.c:105-113 */
+  for (const char *c = seed; *c; ++c) hsh = (hsh << 5) - hsh + (u8)*c;
+  memset(&seeded_state, 0, sizeof seeded_state);
+  initstate_r(hsh, seeded_buf, sizeof seeded_buf, &seeded_state); /* a 128-byte state = rand()'s own generator (TYPE_3), seeded like srand() */
+}
 static u64 random_u64(bool seeded) {
-  if (seeded) return (u64)rand() << 32 | (u64)rand();
+  if (seeded) {
+    int32_t hi = 0, lo = 0;
+    random_r(&seeded_state, &hi), random_r(&seeded_state, &lo); /* _prand64: (u64)rand() << 32 | (u64)rand(), left operand first */
+    return (u64)(u32)hi << 32 | (u64)(u32)lo;
+  }
   static FILE *pool;
   u64 v;
   if (!pool) pool = fopen("/dev/urandom", "rb");

@@ -171,11 +171,8 @@ int main(int argc, const char **argv) {
     return 0;
   }
   run.colour = isatty(fileno(stdout));
-  if (o->seed) { /* a seeded run draws from rand() (the reference free()s an argv pointer here and aborts, main.c:800-805) */
-    u32 s = 5381;
-    for (const char *c = o->seed; *c; ++c) s = s * 33 + (u8)*c;
-    run.seeded = true, srand(s);
-  }
+  if (o->seed) /* a seeded run draws from rand()'s stream (the reference free()s an argv pointer here and aborts, main.c:800-805) */
+    run.seeded = true, seeded_start(o->seed);
   if (!plan_only) filter_open(&run.flt, o->filter);
   if (o->quiet && !o->outfile && !plan_only) { fprintf(stderr, "quiet mode chosen without output file\n"); exit(1); }
   run.a33 = o->addr ? strchr(o->addr, 'c') != NULL : true, run.a65 = o->addr && strchr(o->addr, 'u');

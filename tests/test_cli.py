@@ -155,6 +155,26 @@ def test_add_handed_out_in_the_references_job_size(cli, tmp_path, threads):
 
 
 @pytest.mark.gpu
+def test_rnd_windows_handed_out_in_the_references_job_size(cli, tmp_path):
+    """`rnd -d 128:28 -seed ..` over three windows with the scan handed out in 2^21-key jobs (ECLOOP_HIP_JOB_KEYS: the reference's scheduler;
+    every window is a new scan with a new end, which the host program tells the library): same masks, found lines and per-window summaries
+    as the default hand-out, with the look-ahead and without; few launches per window with it, 128 without."""
+    flt = str(tmp_path / "f.blf")
+    write_blf(flt, synth_bloom_words(1 << 16, 31, "a|(b&c)"))
+    lo, hi = (1 << 167) + 0x1234567, (1 << 168) - 0x7654321
+    args = ["rnd", "-f", flt, "-r", f"{lo:x}:{hi:x}", "-d", "128:28", "-seed", "jobs", "-t", "1"]
+    outs = []
+    for k, extra in enumerate(({}, {"ECLOOP_HIP_JOB_KEYS": str(1 << 21)}, {"ECLOOP_HIP_JOB_KEYS": str(1 << 21), "ECL_HIP_LOOKAHEAD_LOG2": "0"})):
+        env = dict(os.environ, ECLOOP_HIP_RND_WINDOWS="3", ECLOOP_HIP_STATS="1", **extra)
+        lines, status, stdout = run(cli, args, out=str(tmp_path / ("rnd%d.txt" % k)), env=env)
+        masks = [l for l in stdout.splitlines() if re.fullmatch(r"[0-9a-f ]{67}", l)]
+        launches = sum(int(m) for m in re.findall(r"^gpu \d+: (\d+) launches", stdout, re.M))
+        outs.append((lines, counts(status), masks, launches))
+    assert outs[0][:3] == outs[1][:3] == outs[2][:3] and len(outs[0][2]) == 6 and len(outs[0][0]) > 10
+    assert outs[0][3] == 3 and outs[1][3] <= 12 and outs[2][3] == 3 * 128, [o[3] for o in outs]
+
+
+@pytest.mark.gpu
 def test_add_dumps_and_stride(cli, tmp_path):
     ones = str(tmp_path / "ones.blf")
     write_blf(ones, np.full(64, 0xFFFFFFFFFFFFFFFF, np.uint64))
