@@ -1,5 +1,6 @@
 """The C host program (ecloop_amd/host/ecloop-hip): blf-gen / blf-check on the CPU, the search commands on the GPU,
 against the reference's golden outputs (same flags, same output formats, same status counters)."""
+import ctypes as C
 import hashlib
 import json
 import os
@@ -152,6 +153,56 @@ def test_add_handed_out_in_the_references_job_size(cli, tmp_path, threads):
         if k == 1:  # 2^29 keys = 256 jobs: a handful of launches with the look-ahead, one per job without
             assert outs[0] <= 8 + 2 * threads and outs[1] == 256, outs
         assert len(base[0]) > 0
+
+
+@pytest.mark.gpu
+def test_mul_from_a_file_in_batches_equals_the_general_reader_the_pipe_and_the_oracle(cli, tmp_path):
+    """`mul -a cu` over 2^21 + 777 lines of 64 hex digits through a filter that passes one hash in ~300: the batch path straight from the file
+    (several batches on two contexts, AVX-512 / AVX2 decoders), the general reader on the same file, the same bytes through a pipe, CR LF
+    records and `-bin` - one and the same found file, equal to the ORACLE's for every line (orc.mul_hash160_many + blf_has)."""
+    import orc
+    n = (1 << 21) + 777
+    rng = np.random.default_rng(77)
+    b = np.frombuffer(rng.bytes(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    b[5] = 0  # the scalar 0: no point, skipped
+    hexd = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
+    t = np.empty((n, 65), dtype=np.uint8)
+    t[:, 0:64:2], t[:, 1:64:2], t[:, 64] = hexd[b >> 4], hexd[b & 15], 10
+    src = str(tmp_path / "in.txt")
+    t.tofile(src)
+    t2 = np.empty((n, 66), dtype=np.uint8)
+    t2[:, :64], t2[:, 64], t2[:, 65] = t[:, :64], 13, 10
+    crlf = str(tmp_path / "in_crlf.txt")
+    t2.tofile(crlf)
+    binf = str(tmp_path / "in.bin")
+    np.ascontiguousarray(b[:, ::-1]).tofile(binf)
+    words = synth_bloom_words(65539, 41, "a|b")
+    flt = str(tmp_path / "f.blf")
+    write_blf(flt, words)
+    K = np.ascontiguousarray(b[:, ::-1]).view("<u8").reshape(n, 4)
+    h33, h65, ok = orc.mul_hash160_many(K, True, True)
+    L = orc.lib()
+    L.orc_blf_has_many.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    want = []
+    Nn = orc.N
+    for label, hh in (("addr33", h33), ("addr65", h65)):
+        hit = np.zeros(n, np.uint8)
+        L.orc_blf_has_many(words.ctypes.data, len(words), np.ascontiguousarray(hh).ctypes.data, n, hit.ctypes.data)
+        for i in np.nonzero(hit & ok)[0]:
+            want.append("%s\t%s\t%064x" % (label, orc.hex160(hh[i]), int.from_bytes(bytes(b[i]), "big") % Nn))
+    want.sort()
+    assert len(want) > 5000
+    base = ["mul", "-f", flt, "-a", "cu"]
+    runs = {"file": (base, src, {"ECLOOP_HIP_MUL_BATCH_LOG2": "19"}), "file-avx2": (base, src, {"ECLOOP_HIP_NO_AVX512": "1"}),
+            "chunks": (base, src, {"ECLOOP_HIP_MUL_READ": "chunks"}), "crlf": (base, crlf, {}), "bin": (base + ["-bin"], binf, {})}
+    for name, (args, path, extra) in runs.items():
+        lines, status, _ = run(cli, args, stdin_path=path, out=str(tmp_path / (name + ".txt")), env=dict(os.environ, **extra))
+        assert lines == want and counts(status) == (len(want), n), name
+    pr = subprocess.Popen(["cat", src], stdout=subprocess.PIPE)
+    out = str(tmp_path / "pipe.txt")
+    got = subprocess.run([cli] + base + ["-q", "-o", out], stdin=pr.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    pr.wait()
+    assert got.returncode == 0 and sorted(l.rstrip("\n") for l in open(out)) == want
 
 
 @pytest.mark.gpu
