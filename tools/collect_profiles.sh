@@ -160,7 +160,7 @@ if want parity; then
     python tools/full_range_parity.py --filter-n 1100000000 --main-log2 28 --endo-log2 28 2> "$O/parity2.err"; echo "exit code $?"
   } > "$O/full_range_parity.txt"
   cp "$O/full_range_parity.txt" "profiles/${TAG}_full_range_parity.txt"
-  grep -E "^(==|HIP|reference|identical|exit)" "$O/full_range_parity.txt"
+  grep -E "^(==|HIP|reference|bound ref|identical|exit)" "$O/full_range_parity.txt"
 fi
 [ -f "$O/stats.txt" ] && head -8 "$O/stats.txt"
 cat "$O"/pmc*.txt 2>/dev/null | grep -v TRACE | head -80; cat "$O/make_profile.err"

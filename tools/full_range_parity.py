@@ -60,10 +60,18 @@ def main():
         r, rs, rt = run([ref, "add", "-f", blf, "-r", rng, "-t", threads] + extra, os.path.join(tmp, "ref.txt"))
         same = g == r
         ok &= same
+        bound = os.path.join(ROOT, "oracle", "_ref", "ecloop_gpu")  # the reference's own host program on the library, MAX_JOB_SIZE unchanged
+        b = bs = bt = None
+        if os.path.exists(bound):
+            b, bs, bt = run([bound, "add", "-f", blf, "-r", rng, "-t", "1"] + extra, os.path.join(tmp, "bound.txt"))
+            ok &= b == r
         rep += ["", "== %s   -r %s" % (name, rng),
                 "HIP       : %d lines, sha256(sorted) %s, wall %.1f s, status: %s" % (len(g), hashlib.sha256("\n".join(g).encode()).hexdigest()[:16], gt, gs),
                 "reference : %d lines, sha256(sorted) %s, wall %.1f s (-t %s), status: %s" % (len(r), hashlib.sha256("\n".join(r).encode()).hexdigest()[:16], rt, threads, rs),
                 "identical : %s" % same]
+        if b is not None:
+            rep += ["bound ref : %d lines, sha256(sorted) %s, wall %.1f s (the reference's main.c on the library, 2^21-key jobs, -t 1), status: %s" % (
+                len(b), hashlib.sha256("\n".join(b).encode()).hexdigest()[:16], bt, bs), "identical : %s" % (b == r)]
         if not same:
             rep += ["only HIP: %s" % sorted(set(g) - set(r))[:5], "only reference: %s" % sorted(set(r) - set(g))[:5]]
         if not extra:
