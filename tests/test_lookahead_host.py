@@ -349,3 +349,68 @@ def test_one_shard_per_context_stays_one_launch_per_context(L, contexts):
             assert ctxs[t].stats() == (0, 0, 0, 0) and ctxs[t].device()[:2] == (2, n + 64), (t, ctxs[t].stats(), ctxs[t].device())
     finally:
         [c.close() for c in ctxs]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_sequences_from_worker_threads_on_several_devices(L, seed):
+    """the differential fuzz of tools/fuzz_lookahead_gpu.py in the shape hardware here cannot give it: 2 .. 8 worker threads whose contexts sit
+    on 1 .. 8 stand-in devices pull a sequence of calls from one list - mostly the next job of a scan, now and then a jump, a job from
+    behind, one that straddles two jobs, another size, a second scan interleaved - with and without the scan's end told; every call's
+    records are the hit function over its own keys, and no key is launched more than twice (sweeps never overlap; only odd calls that
+    cut across a sweep can repeat keys)"""
+    rnd = random.Random(seed)
+    for trial in range(6):
+        threads = rnd.choice([2, 3, 4, 8])
+        devices = rnd.choice([1, 2, threads])
+        n = rnd.choice([512, 2048, 4096])
+        offs = rnd.choice([0, 0, 64])
+        one_in = rnd.choice([97, 401, 5003])
+        ctxs = [Ctx(L, dev=t % devices, offs=offs, filt=100 + seed, one_in=one_in) for t in range(threads)]
+        A, B = rnd.randrange(1 << 30, 1 << 40), rnd.randrange(1 << 41, 1 << 42)
+        seq, pa, pb = [], 0, 0
+        for _ in range(rnd.choice([300, 1500, 4000])):
+            r = rnd.random()
+            if r < 0.02:
+                pa += rnd.randrange(1, 9) * n
+            elif r < 0.03 and pa > 8 * n:
+                seq.append((A + pa - rnd.randrange(1, 8) * n, n))
+            elif r < 0.04:
+                seq.append((A + pa + n // 2, n))
+            elif r < 0.05:
+                seq.append((A + pa, rnd.choice([1, 77, n // 2, 3 * n])))
+            elif r < 0.10:
+                seq.append((B + pb, n))  # a second scan elsewhere, interleaved now and then
+                pb += n
+                continue
+            seq.append((A + pa, n))
+            pa += n
+        hint = rnd.random() < 0.5
+        results, errors, lock, state = {}, [], threading.Lock(), {"next": 0}
+
+        def worker(c):
+            try:
+                c.set_end((A + pa) << offs if hint else None)
+                while True:
+                    with lock:
+                        i = state["next"]
+                        state["next"] += 1
+                    if i >= len(seq):
+                        return
+                    s, m = seq[i]
+                    rc, got, cnt = c.add(s << offs, m, cap=1 << 15)
+                    assert rc == 0 and cnt == len(got)
+                    results[i] = got
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        try:
+            ts = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errors, errors[0]
+            for i, (s, m) in enumerate(seq):
+                assert same(results[i], ctxs[0].expected(s << offs, m)), (trial, i, hex(s), m)
+            asked = sum(m for _, m in seq)
+            assert sum(c.device()[1] for c in ctxs) <= 2 * asked + (1 << 22) * threads, trial
+        finally:
+            [c.close() for c in ctxs]
