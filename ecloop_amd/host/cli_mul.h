@@ -438,6 +438,7 @@ static void *mul_reader(void *arg) {
     while (q->count == MUL_TEXT_RING) pthread_cond_wait(&q->cv, &q->mu);
     text_chunk *c = &q->ring[q->head];
     pthread_mutex_unlock(&q->mu);
+    if (!c->own && !(c->own = malloc(q->chunk))) { fprintf(stderr, "out of memory for the text buffers\n"); exit(1); }
     c->buf = c->own;
     memcpy(c->buf, carry, have);
     for (ssize_t k; have < q->chunk && (k = read(0, c->buf + have, q->chunk - have)) != 0;) { /* (read, not fread: no second copy through stdio) */
@@ -706,6 +707,10 @@ static size_t mul_batch_records(size_t total) {
   return b;
 }
 
+/* bytes per chunk of the general reader: 64 MB of hex lines (~1 M scalars per device call), 32 MB of pass phrases with -raw.  (256 MB chunks
+   for large files that are not all 64-digit records were measured in round 6: 0.70 against 0.78 G lines/s - the threads fault the mapping's
+   pages in, and larger chunks only make them do it in lock-step.) */
+static size_t mul_general_chunk(const run_t *run) { return run->opt.raw && !run->bin ? MUL_RAW_CHUNK : MUL_TEXT_CHUNK; }
 /* scalars of the largest array a run will hand to a device (bring-up sizes the device staging and the page-locked arrays by it), and
    the window width worth fixing up front when the input's size is known (st_size / 65 lines): the table is built during bring-up, and
    a wider one pays from a size on - 22 bits (1.5 GB, 40 ms; 1.11 G scalars/s on 2^24-scalar calls) below 2^28 lines, 24 bits (5.4 GB,
@@ -718,7 +723,7 @@ static size_t mul_largest_batch(const run_t *run, u32 *window) {
   if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
   (void)rec;
   if (total) return total < batch ? total : batch;
-  return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : MUL_TEXT_CHUNK / MUL_RECORD + 1024;
+  return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : mul_general_chunk(run) / MUL_RECORD + 1024;
 }
 /* the fixed-record path over stdin from `pos`: batches -> arrays -> device threads; returns the records taken */
 static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, size_t rec, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
@@ -780,9 +785,9 @@ static void cmd_mul(run_t *run) {
     if (e && atoi(e) >= 1 && atoi(e) <= MUL_POOL_MAX) P = atoi(e); }
   text_queue tq;
   memset(&tq, 0, sizeof tq);
-  tq.bin = run->bin, tq.chunk = run->opt.raw && !run->bin ? MUL_RAW_CHUNK : MUL_TEXT_CHUNK;
+  tq.bin = run->bin, tq.chunk = MUL_TEXT_CHUNK; /* (the general reader's chunk is decided after the batch path, from what is left: below) */
   pthread_mutex_init(&tq.mu, NULL), pthread_cond_init(&tq.cv, NULL);
-  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = malloc(tq.chunk);
+  for (int i = 0; i < MUL_TEXT_RING; ++i) tq.ring[i].own = tq.ring[i].buf = NULL; /* the reader allocates them if it has to copy (a pipe) */
   scalar_queue sq;
   memset(&sq, 0, sizeof sq);
   sq.run = run, sq.narr = run->ngpus + 2;
@@ -806,6 +811,7 @@ static void cmd_mul(run_t *run) {
     const size_t total = mul_fixed_file_records(run, &pos, &rec);
     if (total) nbatch_records = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
   }
+  tq.chunk = mul_general_chunk(run);
   pthread_create(&reader, NULL, mul_reader, &tq);
   for (;;) {
     t_mark = us_now();
