@@ -389,6 +389,10 @@ typedef struct {
   int head, tail, count; /* filled chunks: [tail, head) */
   bool eof, bin;
   size_t chunk; /* bytes per chunk */
+  size_t limit; /* a seekable input only: stop at the first line end at or after this many bytes (0: read to the end) - cmd_mul then looks
+                   again whether the batch path can go on from there */
+  bool input_done; /* set by the reader: the input is exhausted (not just the stretch it was limited to) */
+  char *map; size_t map_size; /* the mapping the chunks of this stretch point into; cmd_mul unmaps it when they are parsed */
   pthread_mutex_t mu;
   pthread_cond_t cv;
 } text_queue;
@@ -402,9 +406,18 @@ static void *mul_reader(void *arg) {
     char *map = mmap(NULL, size, PROT_READ, MAP_PRIVATE, 0, 0);
     if (map != MAP_FAILED) {
       madvise(map, size, MADV_SEQUENTIAL);
-      for (size_t at = (size_t)pos; at < size;) {
-        size_t end = at + q->chunk < size ? at + q->chunk : size;
-        if (end < size) {
+      q->map = map, q->map_size = size;
+      size_t stop = size; /* where this stretch ends: the first line end at or after pos + limit (records of -bin: a multiple of 32) */
+      if (q->limit && (size_t)pos + q->limit < size) {
+        stop = (size_t)pos + q->limit;
+        if (q->bin) stop = (size_t)pos + (q->limit + 31) / 32 * 32;
+        else
+          while (stop < size && map[stop - 1] != '\n') stop++;
+        if (stop > size) stop = size;
+      }
+      for (size_t at = (size_t)pos; at < stop;) {
+        size_t end = at + q->chunk < stop ? at + q->chunk : stop;
+        if (end < stop) {
           if (q->bin) end = at + (end - at) / 32 * 32;
           else {
             size_t e = end;
@@ -421,13 +434,15 @@ static void *mul_reader(void *arg) {
         pthread_mutex_unlock(&q->mu);
         at = end;
       }
+      if (lseek(0, (off_t)stop, SEEK_SET) < 0) { fprintf(stderr, "[!] lseek on the input failed\n"); exit(1); }
       pthread_mutex_lock(&q->mu);
-      q->eof = true;
+      q->eof = true, q->input_done = stop >= size;
       pthread_cond_broadcast(&q->cv);
       pthread_mutex_unlock(&q->mu);
-      return NULL; /* the mapping stays until exit: the last chunks are still being parsed */
+      return NULL; /* (the mapping stays until the chunks of this stretch are parsed: cmd_mul unmaps it) */
     }
   }
+  q->input_done = true; /* whatever follows reads to the end of the input */
 #ifdef F_SETPIPE_SZ
   (void)fcntl(0, F_SETPIPE_SZ, 1 << 20); /* a pipe on stdin (`cat keys | ecloop-hip mul`): 1 MB instead of 64 KB in flight, fewer wake-ups of the writer */
 #endif
@@ -719,7 +734,14 @@ static size_t mul_general_chunk(const run_t *run) { return run->opt.raw && !run-
 static size_t mul_largest_batch(const run_t *run, u32 *window) {
   off_t pos;
   size_t rec;
-  const size_t total = mul_fixed_file_records(run, &pos, &rec), batch = mul_batch_records(total);
+  size_t total = mul_fixed_file_records(run, &pos, &rec);
+  if (!total && !run->opt.raw && !run->bin && (!getenv("ECLOOP_HIP_MUL_READ") || strcmp(getenv("ECLOOP_HIP_MUL_READ"), "chunks"))) {
+    /* a regular file of hex lines that does not START with a record (a header line, a comment): the batch path will still take most of it
+       (cmd_mul looks again after every stretch of the general reader), so the arrays and the window are sized for that */
+    struct stat stt;
+    if (pos >= 0 && fstat(0, &stt) == 0 && S_ISREG(stt.st_mode) && stt.st_size > pos) total = (size_t)(stt.st_size - pos) / MUL_RECORD;
+  }
+  const size_t batch = mul_batch_records(total);
   if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
   (void)rec;
   if (total) return total < batch ? total : batch;
@@ -805,12 +827,42 @@ static void cmd_mul(run_t *run) {
   pool_init(&pool, P);
   u64 t_text = 0, t_array = 0, t_parse = 0, t_grow = 0, t_pack = 0, nchunks = 0, nfixed = 0, t_mark; /* us per stage (ECLOOP_HIP_STATS) */
   u64 nbatches = 0, nbatch_records = 0;
-  { /* a file of 64-digit lines: whole batches straight from the file; whatever is left (or is not such a file) goes the general way */
+  /* The input is taken in stretches.  A regular file of 64-digit records goes batch by batch straight from the file; where that path meets a
+     batch that holds anything else it stops, the general reader takes that batch's bytes (to the next line end), and the batch path is
+     tried again from there - one odd line, or a commented header, costs one batch at the general reader's rate, not the file.  A file
+     that does not start with a record is read a stretch at a time the general way, looking again after each; a pipe is read to its end. */
+  size_t first_stretch = (size_t)1 << 20;
+  { const char *e = getenv("ECLOOP_HIP_MUL_STRETCH"); /* tests */
+    if (e && atol(e) >= 64) first_stretch = (size_t)atol(e); }
+  int misses = 0;
+  for (;;) {
+  size_t limit = 0;
+  {
     off_t pos;
     size_t rec;
+    struct stat stt;
     const size_t total = mul_fixed_file_records(run, &pos, &rec);
-    if (total) nbatch_records = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
+    const bool file = pos >= 0 && fstat(0, &stt) == 0 && S_ISREG(stt.st_mode);
+    if (total) {
+      const size_t done = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
+      nbatch_records += done;
+      if (pos + (off_t)(done * rec) >= stt.st_size) break; /* the whole file */
+      if (done < total) { /* stopped at a batch that is not all records */
+        const size_t batch = mul_batch_records(total);
+        limit = (total - done < batch ? total - done : batch) * rec;
+      }
+      misses = 0;
+    } else if (file && !run->opt.raw && !run->bin) {
+      if (stt.st_size <= pos) break;
+      /* a header costs 1 MB at the general reader's rate; a file with no records to find doubles the stretch each time, and after 8 looks
+         (256 MB) the general reader keeps the rest (limit 0), which is what it did before there were stretches */
+      limit = misses < 8 ? first_stretch << misses : 0;
+      misses++;
+    }
   }
+  pthread_mutex_lock(&tq.mu);
+  tq.head = tq.tail = tq.count = 0, tq.eof = tq.input_done = false, tq.limit = limit, tq.map = NULL, tq.map_size = 0;
+  pthread_mutex_unlock(&tq.mu);
   tq.chunk = mul_general_chunk(run);
   pthread_create(&reader, NULL, mul_reader, &tq);
   for (;;) {
@@ -895,12 +947,15 @@ static void cmd_mul(run_t *run) {
     pthread_cond_broadcast(&sq.cv);
     pthread_mutex_unlock(&sq.mu);
   }
+  pthread_join(reader, NULL);
+  if (tq.map) munmap(tq.map, tq.map_size); /* every chunk of the stretch has been parsed into an array */
+  if (tq.input_done) break;
+  } /* stretches */
   pthread_mutex_lock(&sq.mu);
   sq.done = true;
   pthread_cond_broadcast(&sq.cv);
   pthread_mutex_unlock(&sq.mu);
   pool_stop(&pool);
-  pthread_join(reader, NULL);
   for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
   if (!run->parse_only) report_close(&run->rep); /* the search is over here: giving back page-locked arrays (0.1 ms per MB) is not part of it */
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);

@@ -650,7 +650,8 @@ def test_mul_parser_file_of_64_digit_lines_in_batches(cli, tmp_path, decoder):
     instruction set: a whole record per AVX-512 load, two AVX2 halves, four SSSE3 quarters) - against fe_modn_from_hex in python ints and
     against the general reader on the same bytes: random values, upper case, values >= n (reduced; top limb all ones is the AVX-512 form's
     slow case), a batch count that does not divide the file; then the same file with a record that is no such line in the middle (the
-    path stops at the batch before it, the general reader takes over) and with a short line + a last line without newline."""
+    path stops at the batch before it, the general reader takes that batch's bytes, the batch path goes on after it) and with a short line +
+    a last line without newline."""
     import random
     r = random.Random(9)
     N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
@@ -683,7 +684,16 @@ def test_mul_parser_file_of_64_digit_lines_in_batches(cli, tmp_path, decoder):
     want, _ = parse(str(bad), ECLOOP_HIP_MUL_READ="chunks")
     assert got == want and len(got) == 50002 and got[-1] == "%064x" % (vals[0] % N) and got[-2] == "%064x" % 0xABC
     assert got[30000] == "%064x" % int(odd[30000][2:], 16) and got[30001] == "%064x" % int(odd[30001][:63], 16)
-    assert "3 batches of fixed records straight from the file (24576 lines)" in stats
+    # batches 0-2 (24576 lines), the fourth batch's bytes through the general reader (it holds the two odd lines), then the batch path again
+    # on the new alignment: 2 more batches before the one that meets the short line and the unterminated last one
+    assert "5 batches of fixed records straight from the file (40960 lines)" in stats
+    # a file that does not START with a record (a header line): the general reader takes the first stretch, the batch path the rest
+    head = tmp_path / "head.txt"
+    head.write_text("0x1f\n# keys\n" + "".join(l + "\n" for l in lines))
+    got, stats = parse(str(head), ECLOOP_HIP_MUL_STRETCH="4096")
+    want, _ = parse(str(head), ECLOOP_HIP_MUL_READ="chunks")
+    m = re.search(r"(\d+) batches of fixed records straight from the file \((\d+) lines\)", stats)
+    assert got == want and got[0] == "%064x" % 0x1F and got[2:] == ["%064x" % (v % N) for v in vals] and m and int(m.group(2)) >= 40000, stats
 
 
 def test_mul_parser_crlf_files_and_binary_files_in_batches(cli, tmp_path):
@@ -707,7 +717,9 @@ def test_mul_parser_crlf_files_and_binary_files_in_batches(cli, tmp_path):
     mixed = tmp_path / "mixed.txt"  # LF records, then CRLF ones: the path ends where the record length changes
     mixed.write_bytes(b"".join(b"%064x\n" % v for v in vals[:10000]) + b"".join(b"%064x\r\n" % v for v in vals[10000:]))
     got, stats = parse(str(mixed))
-    assert got == ["%064x" % (v % N) for v in vals] and "2 batches of fixed records straight from the file (8192 lines)" in stats
+    # 2 batches of LF records, the batch with the change of record length through the general reader, then CR LF records in batches again
+    m = re.search(r"(\d+) batches of fixed records straight from the file \((\d+) lines\)", stats)
+    assert got == ["%064x" % (v % N) for v in vals] and m and int(m.group(1)) >= 6 and int(m.group(2)) >= 24000, stats
     raw = tmp_path / "k.bin"
     raw.write_bytes(b"".join(v.to_bytes(32, "little") for v in vals) + b"\x01\x02\x03")
     got, stats = parse(str(raw), "-bin")
