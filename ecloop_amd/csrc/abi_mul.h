@@ -247,6 +247,59 @@ static int mul_setup_auto(ecl_hip* h, u32 n, u32* W_used) {
   return rc;
 }
 
+// The body of a `mul` call, shared by ecl_hip_mul_batch (scalars from the host) and ecl_hip_mul_batch_raw (scalars hashed on the device from
+// lines of text): n scalars in pieces through the MUL_NBUF device buffers.  copy_in(b, at, m) puts piece [at, at + m)'s input on the copy
+// stream; prepare(b, at, m, &ready) enqueues what else has to happen before the piece's window sums and names the event they wait for
+// (-raw: SHA-256 of the lines into d_kbuf[b], on a stream of its own).  The caller has reset the counters on h->stream and collects the
+// records after it.
+template <class CopyIn, class Prepare> static int mul_pieces(ecl_hip* h, u32 n, const wtab& gtab, const add_args& a, CopyIn copy_in, Prepare prepare) {
+  // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4, 8 and then 10
+  // scalars per resident thread (12 for calls of 2^26 scalars and more), i.e. 196 608 x 1, 2, 4, 8, 10 (12) scalars at three waves per SIMD -
+  // each copy is about as long as the kernel before it.  More scalars per thread share an inversion among more of them but park more sums
+  // (144 bytes each: at 16 per thread a piece parks 453 MB, past the Infinity Cache) and lengthen the pipeline's fill and drain:
+  // tools/ab_mul_topr.sh (profiles/r04_mul_sched.txt, three waves per SIMD): 2^24-scalar calls 1252 / 1277 / 1252 / 1199 M scalars/s at
+  // 8 / 10 / 12 / 16 per thread, 2^25: 1313 / 1320 / 1319 / 1291, 2^26: 1354 / 1330 / 1346 / 1324, 2^27: 1368 / 1367 / 1378 / 1340.
+  // Round 4's earlier measurements at two waves per SIMD (tools/mul_kernel_times.sh, profiles/r04_mul_split.txt): 8 per thread 0.888 ms per
+  // piece = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s, 32 per thread lose; doubling first pieces 1222-1230 / 1261-1270
+  // on 2^24 / 2^26-scalar calls against 1214 / 1253 for a 2^18-scalar piece followed at once by full ones; two staging buffers 1208 / 1249.
+  // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
+  // Round 5: the pieces alternate between TWO compute streams (each with its own parking space).  A piece's 768 workgroups are all
+  // resident at once and do the same work, but they do not end together; on one stream the next piece's first workgroup waits for the
+  // last of this one.  On two streams the next piece's workgroups move into the slots as they fall free (ECL_HIP_MUL_STREAMS=1: one stream).
+  static const u32 first_R = env_u32("ECL_HIP_MUL_FIRST_R", 1u, 1u, MUL_R);   // tuning hooks (A/B runs)
+  static const u32 grow_pct = env_u32("ECL_HIP_MUL_GROW", 200u, 100u, 1600u);
+  static const u32 top_R = env_u32("ECL_HIP_MUL_TOP_R", 0u, 0u, MUL_R);
+  static const u32 nstreams = env_u32("ECL_HIP_MUL_STREAMS", 2u, 1u, 2u);
+  const u64 unit = (u64)mul_nt_target();
+  const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 26) ? 12u : 10u));
+  const u32 top = h->kbuf_cap < top_want ? h->kbuf_cap : (u32)top_want;
+  u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // the second stream starts behind the counters' reset (and behind the call before)
+  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
+    const u32 b = c % MUL_NBUF;
+    const int lane = (int)(c % nstreams);
+    hipStream_t st = lane ? h->stream2 : h->stream;
+    m = n - at < lim ? n - at : lim;
+    // no crumb at the end: what would be left after this piece is taken along if it is less than half a piece (a 2^24-scalar call used to
+    // end on a 65 536-scalar launch - a third of the chip, one inversion per scalar - that took 0.10 ms, 0.8 % of the call)
+    if (n - at - m < lim / 2 && n - at <= h->kbuf_cap && (u64)(n - at) <= unit * MUL_R) m = n - at;
+    if (c >= MUL_NBUF) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel MUL_NBUF pieces back is done with this buffer (and its staging twin)
+    if (int rc = copy_in(b, at, m)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
+    hipEvent_t ready = h->ev_copied[b];
+    if (int rc = prepare(b, at, m, &ready)) return rc;
+    HIPCHK(h, hipStreamWaitEvent(st, ready, 0));
+    mul_launch_piece(h, lane, h->d_kbuf[b], m, at, gtab, a);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_free[b], st));
+  }
+  HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));  // the context's stream goes on (list confirm, counters) when both are done
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  return ECL_OK;
+}
+
 extern "C" int ecl_hip_reserve_mul(ecl_hip* h, uint32_t n, uint32_t cap) {
   if (!h || n == 0 || cap > ECL_CAP_MAX) return ECL_E_ARG;
   HIPCHK(h, hipSetDevice(h->dev));
@@ -305,50 +358,17 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 2 * sizeof(u32), h->stream));
   // Scalars are used as given (4 little-endian u64 = 8 u32 words): the window sum (wtab_sum_fast, any width) is k*G for any
   // 256-bit k, which is (k mod n)*G; k = 0 (mod n) gives the point at infinity and is skipped.
-  // A call is cut into pieces so that the copy engine runs ahead of the kernel (MUL_NBUF device buffers): pieces of 1, 2, 4, 8 and then 10
-  // scalars per resident thread (12 for calls of 2^26 scalars and more), i.e. 196 608 x 1, 2, 4, 8, 10 (12) scalars at three waves per SIMD -
-  // each copy is about as long as the kernel before it.  More scalars per thread share an inversion among more of them but park more sums
-  // (144 bytes each: at 16 per thread a piece parks 453 MB, past the Infinity Cache) and lengthen the pipeline's fill and drain:
-  // tools/ab_mul_topr.sh (profiles/r04_mul_sched.txt, three waves per SIMD): 2^24-scalar calls 1252 / 1277 / 1252 / 1199 M scalars/s at
-  // 8 / 10 / 12 / 16 per thread, 2^25: 1313 / 1320 / 1319 / 1291, 2^26: 1354 / 1330 / 1346 / 1324, 2^27: 1368 / 1367 / 1378 / 1340.
-  // Round 4's earlier measurements at two waves per SIMD (tools/mul_kernel_times.sh, profiles/r04_mul_split.txt): 8 per thread 0.888 ms per
-  // piece = 1.18 G scalars/s (22-bit table), 16 per thread 1.763 ms = 1.19 G/s, 32 per thread lose; doubling first pieces 1222-1230 / 1261-1270
-  // on 2^24 / 2^26-scalar calls against 1214 / 1253 for a 2^18-scalar piece followed at once by full ones; two staging buffers 1208 / 1249.
-  // (in units of one scalar per chain = what the chip holds at once: 2^17 scalars at two waves per SIMD: 2^18, then 2^20 / 2^21)
-  // Round 5: the pieces alternate between TWO compute streams (each with its own parking space).  A piece's 768 workgroups are all
-  // resident at once and do the same work, but they do not end together; on one stream the next piece's first workgroup waits for the
-  // last of this one.  On two streams the next piece's workgroups move into the slots as they fall free (ECL_HIP_MUL_STREAMS=1: one stream).
-  static const u32 first_R = env_u32("ECL_HIP_MUL_FIRST_R", 1u, 1u, MUL_R);   // tuning hooks (A/B runs)
-  static const u32 grow_pct = env_u32("ECL_HIP_MUL_GROW", 200u, 100u, 1600u);
-  static const u32 top_R = env_u32("ECL_HIP_MUL_TOP_R", 0u, 0u, MUL_R);
-  static const u32 nstreams = env_u32("ECL_HIP_MUL_STREAMS", 2u, 1u, 2u);
-  const u64 unit = (u64)mul_nt_target();
-  const u64 top_want = unit * (top_R ? top_R : (n >= (1u << 26) ? 12u : 10u));
-  const u32 top = h->kbuf_cap < top_want ? h->kbuf_cap : (u32)top_want;
-  u32 lim = top < unit * first_R ? top : (u32)(unit * first_R);
-  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // the second stream starts behind the counters' reset (and behind the call before)
-  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-  for (u32 at = 0, c = 0, m = 0; at < n; at += m, ++c, lim = (u64)lim * grow_pct / 100 <= top ? (u32)((u64)lim * grow_pct / 100) & ~1023u : top) {
-    const u32 b = c % MUL_NBUF;
-    const int lane = (int)(c % nstreams);
-    hipStream_t st = lane ? h->stream2 : h->stream;
-    m = n - at < lim ? n - at : lim;
-    // no crumb at the end: what would be left after this piece is taken along if it is less than half a piece (a 2^24-scalar call used to
-    // end on a 65 536-scalar launch - a third of the chip, one inversion per scalar - that took 0.10 ms, 0.8 % of the call)
-    if (n - at - m < lim / 2 && n - at <= h->kbuf_cap && (u64)(n - at) <= unit * MUL_R) m = n - at;
-    if (c >= MUL_NBUF) HIPCHK(h, hipEventSynchronize(h->ev_free[b]));  // the kernel MUL_NBUF pieces back is done with this buffer (and its staging twin)
-    const void* src = scalars[at];
-    if (!direct) memcpy(h->pin_k[b], scalars[at], (size_t)m * 32), src = h->pin_k[b];
-    HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipEventRecord(h->ev_copied[b], h->copy_stream));
-    HIPCHK(h, hipStreamWaitEvent(st, h->ev_copied[b], 0));
-    mul_launch_piece(h, lane, h->d_kbuf[b], m, at, gtab, a);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev_free[b], st));
-  }
-  HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));  // the context's stream goes on (list confirm, counters) when both are done
-  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  const bool staged = !direct;
+  rc = mul_pieces(
+      h, n, gtab, a,
+      [&](u32 b, u32 at, u32 m) -> int {  // piece `at`'s scalars onto the copy stream
+        const void* src = scalars[at];
+        if (staged) memcpy(h->pin_k[b], scalars[at], (size_t)m * 32), src = h->pin_k[b];
+        HIPCHK(h, hipMemcpyAsync(h->d_kbuf[b], src, (size_t)m * 32, hipMemcpyHostToDevice, h->copy_stream));
+        return ECL_OK;
+      },
+      [](u32, u32, u32, hipEvent_t*) -> int { return ECL_OK; });
+  if (rc != ECL_OK) return rc;
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   u32 cnt = 0;
   rc = collect_found(h, cap, rcap, out, &cnt, false);
@@ -361,12 +381,14 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   return rc;
 }
 
-// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests.  One chunk per call (the caller
-// cuts: n <= 2^22 lines); text and line table cross PCIe on the copy stream, hashing and the window sums follow on the
-// context's stream.  Two contexts per GPU overlap one call's copies with the other's kernels, as for ecl_hip_mul_batch.
+// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests (n <= 2^26 lines a call).  The text crosses PCIe
+// first, whole (a line may lie anywhere in it); the line table follows piece by piece on the copy stream, and every piece hashes its lines
+// into its staging buffer in front of its window sums, on the piece's compute stream - the pieces of ecl_hip_mul_batch, with 8 bytes of
+// table + the line instead of 32 bytes of scalar.  (Until round 6 a call was ONE piece of at most 2^22 lines on one stream, and the host
+// program made ~2 M-line calls: 0.79-0.87 G lines/s over 2^30 pass phrases against 1.25 for hex lines.)
 extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t text_bytes, const uint64_t* lines, uint32_t n, ecl_found* out,
                                      uint32_t cap, uint32_t* nout) {
-  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_CHUNK || text_bytes > 0xFFFFFFF0u || cap > ECL_CAP_MAX) return ECL_E_ARG;
+  if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_RAW_MAX || text_bytes > 0xFFFFFFF0u || cap > ECL_CAP_MAX) return ECL_E_ARG;
   *nout = 0;
   if (!h->d_bloom) return ECL_E_NOBLOOM;
   if (n == 0) return ECL_OK;
@@ -382,7 +404,9 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   const size_t text_words = ((size_t)text_bytes + 3) / 4 + 2;  // two spare words: the gather reads one word past the last byte
   if (text_words > h->rawtext_cap || n > h->rawlines_cap) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream2));
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    if (h->prep_stream) HIPCHK(h, hipStreamSynchronize(h->prep_stream));  // (a call that failed between its pieces)
     if (text_words > h->rawtext_cap) {
       if (h->d_rawtext) HIPCHK(h, hipFree(h->d_rawtext));
       h->d_rawtext = nullptr, h->rawtext_cap = 0;
@@ -403,30 +427,70 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
       h->rawlines_cap = capl;
     }
   }
+  if (!h->prep_stream) {
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (numerically lower = higher priority)
+    static const u32 prio = env_u32("ECL_HIP_RAW_PRIORITY", 1u, 0u, 1u);  // A/B hook
+    HIPCHK(h, hipStreamCreateWithPriority(&h->prep_stream, hipStreamNonBlocking, prio ? hi : lo));
+    for (int i = 0; i < MUL_NBUF; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_hashed[i], hipEventDisableTiming));
+  }
   add_args a;
   memset(&a, 0, sizeof a);
   a.bloom = bloom_make(h->d_bloom, h->bloom_words);
   a.found = h->d_found, a.counter = h->d_counter, a.cap = rcap;
-  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 3 * sizeof(u32), h->stream));
-  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_rawtext, text, text_bytes, hipMemcpyHostToDevice, h->copy_stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_rawlines, lines, (size_t)n * 8, hipMemcpyHostToDevice, h->copy_stream));
-  HIPCHK(h, hipEventRecord(h->ev_copied[0], h->copy_stream));
-  HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_copied[0], 0));
-  hipLaunchKernelGGL(k_raw_scalars, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_rawtext, text_bytes, h->d_rawlines, n, h->d_kbuf[0], h->d_counter + 2);
-  mul_launch_piece(h, 0, h->d_kbuf[0], n, 0u, gtab, a);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-  u32 cnt = 0;
-  rc = collect_found(h, cap, rcap, out, &cnt, false);
-  *nout = cnt;
-  u32 bad = 0;
-  HIPCHK(h, hipMemcpy(&bad, h->d_counter + 2, sizeof bad, hipMemcpyDeviceToHost));
-  if (bad) {
+  u64* d_lines = h->d_rawlines;
+  u32* d_flags = h->d_counter + 2;  // [0] a line outside the text, [1] a line beyond the part of the text that was on the device when it was hashed
+  u32* d_text = h->d_rawtext;
+  // The text goes with the pieces: in front of piece c's share of the table, the text up to the end of that share's LAST line - for a
+  // table in the order of the text (any caller that cut lines out of a buffer front to back) every line is then on the device when its
+  // piece is hashed, and the first piece starts after its own bytes instead of after all of them (300 MB for 2^24 pass phrases: 5 ms of
+  // a 20 ms call).  The kernel checks it line by line; a table in another order raises flag [1], and the call is run again with the
+  // whole text sent first.  Page-locked text and table (ecl_hip_alloc_host) go by DMA from where they are.
+  u32 flags[2] = {0, 0}, cnt = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool in_order = pass == 0;
+    HIPCHK(h, hipMemsetAsync(h->d_counter, 0, 4 * sizeof(u32), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));  // the hashing writes the flags: behind their reset
+    HIPCHK(h, hipStreamWaitEvent(h->prep_stream, h->ev_fork, 0));
+    u32 have = 0;  // bytes of the text on the copy stream so far
+    if (!in_order) {
+      HIPCHK(h, hipMemcpyAsync(d_text, text, text_bytes, hipMemcpyHostToDevice, h->copy_stream));
+      have = text_bytes;
+    }
+    rc = mul_pieces(
+        h, n, gtab, a,
+        [&](u32, u32 at, u32 m) -> int {  // (the copy stream is in order: the piece's table is behind its text)
+          const u64 last = lines[at + m - 1], end = (last & 0xFFFFFFFFull) + (last >> 32);
+          const u32 want = at + m == n || end > text_bytes ? text_bytes : (u32)end;
+          if (want > have) {
+            HIPCHK(h, hipMemcpyAsync((uint8_t*)d_text + have, text + have, want - have, hipMemcpyHostToDevice, h->copy_stream));
+            have = want;
+          }
+          HIPCHK(h, hipMemcpyAsync(d_lines + at, lines + at, (size_t)m * 8, hipMemcpyHostToDevice, h->copy_stream));
+          return ECL_OK;
+        },
+        [&](u32 b, u32 at, u32 m, hipEvent_t* ready) -> int {
+          // The hashing has a stream of its own, of higher priority than the compute streams, and runs up to MUL_NBUF - 1 pieces ahead like
+          // the copies: on the piece's compute stream it would sit between two k_mul_check launches that each fill the chip.
+          HIPCHK(h, hipStreamWaitEvent(h->prep_stream, h->ev_copied[b], 0));
+          hipLaunchKernelGGL(k_raw_scalars, dim3((m + 255) / 256), dim3(256), 0, h->prep_stream, d_text, text_bytes, have, d_lines + at, m, h->d_kbuf[b], d_flags);
+          HIPCHK(h, hipEventRecord(h->ev_hashed[b], h->prep_stream));
+          *ready = h->ev_hashed[b];
+          return ECL_OK;
+        });
+    if (rc != ECL_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    rc = collect_found(h, cap, rcap, out, &cnt, false);  // (the one wait of the call; the flags come back with the counters)
+    if (rc != ECL_OK && rc != ECL_E_OVERFLOW) return rc;
+    flags[0] = h->pin_counter[2], flags[1] = h->pin_counter[3];
+    if (flags[0] || !flags[1]) break;
+  }
+  if (flags[0]) {
     h->err = "mul_batch_raw: a line of the table lies outside the text";
-    *nout = 0;
+    h->last_held = h->last_total = 0;
     return ECL_E_ARG;
   }
+  *nout = cnt;
   if (rc == ECL_OK || rc == ECL_E_OVERFLOW) {
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));

@@ -58,9 +58,10 @@ struct ecl_hip {
   u32* d_rawtext = nullptr; size_t rawtext_cap = 0; u64* d_rawlines = nullptr; u32 rawlines_cap = 0;  // `mul -raw`: text and line table of one call
   hipStream_t copy_stream = nullptr, stream2 = nullptr;  // `mul`: the copy engine's stream; the second compute stream (pieces alternate)
   hipEvent_t ev_copied[MUL_NBUF] = {}, ev_free[MUL_NBUF] = {}, ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t prep_stream = nullptr; hipEvent_t ev_hashed[MUL_NBUF] = {};  // `mul -raw`: the lines are hashed on a stream of their own, ahead of the pieces
   u32* d_list = nullptr; u64 list_n = 0;       // optional sorted hash list (exact confirm on the device)
   ecl_found_dev* d_found = nullptr; u32 found_cap = 0;
-  u32* d_counter = nullptr;
+  u32* d_counter = nullptr; u32* pin_counter = nullptr;  // (the counters' page-locked host copy: read back by the copy engine, no compute slot needed)
   // records of the last add_range / mul_batch call that are still on the device (ecl_hip_fetch_found): where they start in d_found,
   // how many the device holds, the call's total, and whether the endo byte is meaningful
   u32 last_at = 0, last_held = 0, last_total = 0; bool last_endo = false;
@@ -141,7 +142,8 @@ int ecl_hip_open(ecl_hip** out, int device, uint32_t flags, uint32_t ord_offs) {
   HIPCHK(h, hipEventCreate(&h->ev_s1));
   HIPCHK(h, hipMalloc(&h->d_aux, 34 * 16 * sizeof(u32)));
   HIPCHK(h, hipMalloc(&h->d_auxk, 34 * 8 * sizeof(u32)));
-  HIPCHK(h, hipMalloc(&h->d_counter, 4 * sizeof(u32)));  // [0] records appended, [1] records confirmed by the list, [2] bad-input flag of mul_batch_raw
+  HIPCHK(h, hipMalloc(&h->d_counter, 4 * sizeof(u32)));  // [0] records appended, [1] records confirmed by the list, [2] [3] input flags of mul_batch_raw
+  HIPCHK(h, hipHostMalloc((void**)&h->pin_counter, 4 * sizeof(u32), hipHostMallocDefault));
   // the self-test checks the CODE (known answers, walk kernel against the double-and-add kernel): once per process
   // for every (device, kernel selection) is enough - eight handles for eight shards of one scan do not repeat it
   static std::mutex mu;
@@ -166,16 +168,20 @@ void ecl_hip_close(ecl_hip* h) {
   (void)hipSetDevice(h->dev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  if (h->prep_stream) (void)hipStreamSynchronize(h->prep_stream);
   (void)hipFree(h->d_tab), (void)hipFree(h->d_gtab), (void)hipFree(h->d_aux), (void)hipFree(h->d_auxk), (void)hipFree(h->d_cxy), (void)hipFree(h->d_ctab);
   (void)hipFree(h->d_scr), (void)hipFree(h->d_scr2), (void)hipFree(h->d_bloom), (void)hipFree(h->d_list), (void)hipFree(h->d_found), (void)hipFree(h->d_counter);
+  if (h->pin_counter) (void)hipHostFree(h->pin_counter);
   for (int i = 0; i < MUL_NBUF; ++i) {
     (void)hipFree(h->d_kbuf[i]);
     if (h->pin_k[i]) (void)hipHostFree(h->pin_k[i]);
     if (h->ev_copied[i]) (void)hipEventDestroy(h->ev_copied[i]);
     if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
+    if (h->ev_hashed[i]) (void)hipEventDestroy(h->ev_hashed[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->prep_stream) (void)hipStreamDestroy(h->prep_stream);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   (void)hipFree(h->d_multmp[0]), (void)hipFree(h->d_multmp[1]), (void)hipFree(h->d_ver), (void)hipFree(h->d_rawtext), (void)hipFree(h->d_rawlines);
@@ -417,8 +423,11 @@ static int collect_found(ecl_hip* h, u32 cap, u32 rcap, ecl_found* out, u32* nou
                        h->d_found + rcap, h->d_counter + 1, rcap);
     HIPCHK(h, hipGetLastError());
   }
-  u32 cnts[2] = {0, 0};
-  HIPCHK(h, hipMemcpyAsync(cnts, h->d_counter, sizeof cnts, hipMemcpyDeviceToHost, h->stream));
+  // One read-back and one wait per call, into page-locked memory: a copy into pageable memory goes through a staging kernel, and with
+  // a second context's k_mul_check launches filling the chip every small kernel waits milliseconds for a slot (each such wait at the
+  // end of a `mul` call is time this context has nothing in flight).  All four words: mul_batch_raw reads its flags from the same copy.
+  u32* cnts = h->pin_counter;
+  HIPCHK(h, hipMemcpyAsync(cnts, h->d_counter, 4 * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const u32 cnt = lst ? cnts[1] : cnts[0];
   const u32 take = cnt < cap ? cnt : cap;

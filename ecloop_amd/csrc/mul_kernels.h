@@ -14,6 +14,7 @@
 #define MUL_NBUF 4  /* staging buffers of ecl_hip_mul_batch: the copy engine runs up to MUL_NBUF - 1 pieces ahead of the kernel */
 #endif
 #define MUL_CHUNK (1u << 22)  /* scalars per staged chunk of ecl_hip_mul_batch (128 MB): 2^18 threads x MUL_R */
+#define MUL_RAW_MAX (1u << 26) /* lines per ecl_hip_mul_batch_raw call (a 512 MB line table on the device) */
 #define GT_WINDOWS 19u
 #define GT_PER ((1u << GT_W) - 1u)
 // k*G as a sum of table points, one per non-zero W-bit digit of k (LSB-first windows, ec_gtable_mul lib/ecc.c:907-929):
@@ -367,14 +368,17 @@ __device__ __forceinline__ xyzz wtab_sum_fast(const u32* __restrict__ kw, const 
 // gathered from the text (any alignment: two aligned words and a funnel shift per message word), padded per FIPS 180-4 and
 // compressed block by block; the digest, read as a big-endian 256-bit number, is written where k_mul_check expects the
 // scalar (8 little-endian words).  lines[i] = start | length << 32, offsets into `text`; `text` carries 8 spare bytes.
-__global__ void __launch_bounds__(256) k_raw_scalars(const u32* __restrict__ text, u32 text_bytes, const u64* __restrict__ lines, u32 n, u32* __restrict__ out,
-                                                      u32* __restrict__ bad) {
+// text_have <= text_bytes: the part of the text that is on the device when this launch runs (the host sends the text along with the
+// pieces of the table); a line beyond it raises bad[1] - the host then repeats the call with all of the text sent first.
+__global__ void __launch_bounds__(256) k_raw_scalars(const u32* __restrict__ text, u32 text_bytes, u32 text_have, const u64* __restrict__ lines, u32 n,
+                                                      u32* __restrict__ out, u32* __restrict__ bad) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const u64 ln = lines[i];
   const u32 start = (u32)ln;
   u32 L = (u32)(ln >> 32);
-  if ((u64)start + L > text_bytes) *bad = 1, L = 0;  // a line outside the text: the call is refused (ECL_E_ARG), nothing is read there
+  if ((u64)start + L > text_bytes) bad[0] = 1, L = 0;  // a line outside the text: the call is refused (ECL_E_ARG), nothing is read there
+  else if (start + L > text_have) bad[1] = 1, L = 0;    // not here yet
   u32 st[8];
   sha256_init(st);
   const u32 nblk = (L + 9u + 63u) >> 6;

@@ -381,7 +381,40 @@ static void *copy_worker(void *arg) {
 
 /* text chunks: reader thread -> parser */
 #define MUL_TEXT_CHUNK ((size_t)64 << 20) /* hex lines and -bin: ~1 M / 2 M scalars per chunk */
-#define MUL_RAW_CHUNK ((size_t)32 << 20)  /* -raw: pass phrases are a quarter as long as hex keys - ~2 M lines per chunk */
+#define MUL_RAW_CHUNK ((size_t)32 << 20)  /* -raw from a pipe: pass phrases are a quarter as long as hex keys - ~2 M lines per chunk */
+#define MUL_RAW_CHUNK_MAX ((size_t)256 << 20) /* -raw from a regular file: an eighth of the file up to this (~15 M lines = one device call) */
+/* bytes per -raw chunk = per ecl_hip_mul_batch_raw call.  The device reaches its rate on calls of 2^24 scalars (a call is pipelined inside
+   the library, and its first and last pieces run on a part-filled chip), so a file large enough is read in chunks of 256 MB; a small
+   file keeps ~8 chunks so that its contexts still take turns; a pipe keeps 32 MB (what is read is what can be worked on) */
+static size_t mul_raw_chunk(void) {
+  static size_t chunk;
+  if (!chunk) {
+    struct stat st;
+    const off_t pos = lseek(0, 0, SEEK_CUR);
+    chunk = MUL_RAW_CHUNK;
+    if (pos >= 0 && fstat(0, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > pos) {
+      const size_t want = (size_t)(st.st_size - pos) / 8 & ~(((size_t)1 << 20) - 1);
+      chunk = want < MUL_RAW_CHUNK ? MUL_RAW_CHUNK : want > MUL_RAW_CHUNK_MAX ? MUL_RAW_CHUNK_MAX : want;
+    }
+    const char *e = getenv("ECLOOP_HIP_MUL_RAW_CHUNK"); /* experiments: bytes */
+    if (e && atol(e) >= 4096) chunk = (size_t)atol(e);
+  }
+  return chunk;
+}
+/* lines a regular file of -raw input holds, estimated from the line lengths of its first 256 KB (0: not a regular file); decides the
+   window width during bring-up as st_size / 65 does for hex lines */
+static size_t mul_raw_lines_estimate(void) {
+  struct stat st;
+  const off_t pos = lseek(0, 0, SEEK_CUR);
+  if (pos < 0 || fstat(0, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= pos) return 0;
+  static char head[256 << 10];
+  const ssize_t got = pread(0, head, sizeof head, pos);
+  if (got <= 0) return 0;
+  size_t nl = 0;
+  for (ssize_t i = 0; i < got; ++i) nl += head[i] == '\n';
+  if (!nl) nl = 1;
+  return (size_t)((double)(st.st_size - pos) * (double)nl / (double)got);
+}
 #define MUL_TEXT_RING 3
 typedef struct { char *buf, *own; size_t len; } text_chunk; /* buf = own (a ring buffer) or a slice of the mapped input */
 typedef struct {
@@ -549,7 +582,7 @@ static void *mul_prealloc(void *arg) {
   for (int i = 0; i < want && i < MUL_MAX_ARRAYS; ++i) {
     scalar_array ar;
     memset(&ar, 0, sizeof ar);
-    if (raw) raw_grow(a->run, &ar, MUL_RAW_CHUNK, MUL_RAW_CHUNK / 12);
+    if (raw) raw_grow(a->run, &ar, mul_raw_chunk(), mul_raw_chunk() / 12);
     else ks_grow(a->run, &ar, per);
     mul_ready_arrays[i] = ar, mul_ready_count = i + 1;
   }
@@ -569,7 +602,7 @@ typedef struct { scalar_queue *q; int g; u64 busy_us, wait_us, calls, scalars; }
 static void *mul_device_worker(void *arg) {
   mul_dev_arg *a = arg;
   scalar_queue *q = a->q;
-  const size_t STEP = 1u << 22, WHOLE = (size_t)1 << 26; /* lines per -raw call (the ABI's limit); scalars per call otherwise: the array as it is */
+  const size_t STEP = 1u << 26, WHOLE = (size_t)1 << 26; /* lines per -raw call (the ABI's limit); scalars per call otherwise: the array as it is */
   for (;;) {
     u64 t_mark = us_now();
     pthread_mutex_lock(&q->mu);
@@ -722,10 +755,10 @@ static size_t mul_batch_records(size_t total) {
   return b;
 }
 
-/* bytes per chunk of the general reader: 64 MB of hex lines (~1 M scalars per device call), 32 MB of pass phrases with -raw.  (256 MB chunks
+/* bytes per chunk of the general reader: 64 MB of hex lines (~1 M scalars per device call), 32 ... 256 MB of pass phrases with -raw (mul_raw_chunk).  (256 MB chunks
    for large files that are not all 64-digit records were measured in round 6: 0.70 against 0.78 G lines/s - the threads fault the mapping's
    pages in, and larger chunks only make them do it in lock-step.) */
-static size_t mul_general_chunk(const run_t *run) { return run->opt.raw && !run->bin ? MUL_RAW_CHUNK : MUL_TEXT_CHUNK; }
+static size_t mul_general_chunk(const run_t *run) { return run->opt.raw && !run->bin ? mul_raw_chunk() : MUL_TEXT_CHUNK; }
 /* scalars of the largest array a run will hand to a device (bring-up sizes the device staging and the page-locked arrays by it), and
    the window width worth fixing up front when the input's size is known (st_size / 65 lines): the table is built during bring-up, and
    a wider one pays from a size on - 22 bits (1.5 GB, 40 ms; 1.11 G scalars/s on 2^24-scalar calls) below 2^28 lines, 24 bits (5.4 GB,
@@ -745,7 +778,12 @@ static size_t mul_largest_batch(const run_t *run, u32 *window) {
   if (window) *window = !total ? 0 : total < ((size_t)1 << 28) ? 22 : total < ((size_t)1 << 31) ? 24 : 26;
   (void)rec;
   if (total) return total < batch ? total : batch;
-  return run->bin ? MUL_TEXT_CHUNK / 32 : run->opt.raw ? MUL_RAW_CHUNK / 12 : mul_general_chunk(run) / MUL_RECORD + 1024;
+  if (run->opt.raw && !run->bin) {
+    const size_t est = mul_raw_lines_estimate();
+    if (window && est) *window = est < ((size_t)1 << 28) ? 22 : est < ((size_t)1 << 31) ? 24 : 26;
+    return mul_raw_chunk() / 12;
+  }
+  return run->bin ? MUL_TEXT_CHUNK / 32 : mul_general_chunk(run) / MUL_RECORD + 1024;
 }
 /* the fixed-record path over stdin from `pos`: batches -> arrays -> device threads; returns the records taken */
 static size_t mul_fixed_file_run(run_t *run, pool_t *pool, int P, scalar_queue *sq, off_t pos, size_t total, size_t rec, u64 *t_array, u64 *t_grow, u64 *t_parse, u64 *nbatches) {
@@ -835,6 +873,8 @@ static void cmd_mul(run_t *run) {
   { const char *e = getenv("ECLOOP_HIP_MUL_STRETCH"); /* tests */
     if (e && atol(e) >= 64) first_stretch = (size_t)atol(e); }
   int misses = 0;
+  char *last_map = NULL;
+  size_t last_map_size = 0;
   for (;;) {
   size_t limit = 0;
   {
@@ -948,8 +988,12 @@ static void cmd_mul(run_t *run) {
     pthread_mutex_unlock(&sq.mu);
   }
   pthread_join(reader, NULL);
-  if (tq.map) munmap(tq.map, tq.map_size); /* every chunk of the stretch has been parsed into an array */
-  if (tq.input_done) break;
+  /* every chunk of the stretch has been parsed into an array.  The LAST mapping is left alone until the devices are done: munmap of 18 GB
+     of touched pages holds the process's address-space lock for 0.2 s, and the device threads' launches and copies stood still behind it
+     (rocprofv3 --hip-runtime-trace: one hipLaunchKernel of 220 ms and one hipMemcpyAsync of 217 ms, both threads at once - a fifth of
+     a 2^30-line -raw run) */
+  if (tq.input_done) { last_map = tq.map, last_map_size = tq.map_size; break; }
+  if (tq.map) munmap(tq.map, tq.map_size);
   } /* stretches */
   pthread_mutex_lock(&sq.mu);
   sq.done = true;
@@ -958,6 +1002,7 @@ static void cmd_mul(run_t *run) {
   pool_stop(&pool);
   for (int g = 0; g < run->ngpus; ++g) pthread_join(devth[g], NULL);
   if (!run->parse_only) report_close(&run->rep); /* the search is over here: giving back page-locked arrays (0.1 ms per MB) is not part of it */
+  if (last_map) munmap(last_map, last_map_size);
   for (int i = 0; i < MUL_TEXT_RING; ++i) free(tq.ring[i].own);
   for (int i = 0; i < sq.narr; ++i) { /* (page-locked arrays are left to the end of the process, which follows: unlocking 2 GB takes 0.2 s) */
     if (!sq.arr[i].pinned) ks_free(run, sq.arr[i].ks, false);

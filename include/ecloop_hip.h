@@ -148,10 +148,11 @@ int ecl_hip_verify(ecl_hip *h, const uint64_t (*k)[4], uint32_t n, uint32_t (*h3
 
 /* `mul -raw` (main.c:505-527: the scalar of a line is the SHA-256 of its bytes, read as a big-endian number): the same as
    ecl_hip_mul_batch with the hashing done on the device.  `text` holds the lines' bytes (anywhere, in any order, newline
-   bytes or not), lines[i] = offset of line i in `text` (low 32 bits) | its length in bytes (high 32 bits); n <= 2^22 lines
+   bytes or not), lines[i] = offset of line i in `text` (low 32 bits) | its length in bytes (high 32 bits); n <= 2^26 lines
    and text_bytes < 2^32 - 16 per call, every line inside the text (ECL_E_ARG otherwise).  key_offset of a hit = line
    index; the caller re-derives that line's private key (one SHA-256) for the found record.  Page-locked `text` / `lines`
-   arrays are read by DMA directly. */
+   arrays are read by DMA directly; a call is pipelined like ecl_hip_mul_batch's (the table and the hashing piece by piece), so large
+   calls (2^24 lines) run at the rate of large ecl_hip_mul_batch calls. */
 int ecl_hip_mul_batch_raw(ecl_hip *h, const uint8_t *text, uint32_t text_bytes, const uint64_t *lines, uint32_t n, ecl_found *out,
                           uint32_t cap, uint32_t *nout);
 

@@ -650,6 +650,57 @@ def test_mul_batch_raw_hashes_lines_on_the_device():
         d.close()
 
 
+def test_mul_batch_raw_in_pieces_table_in_any_order_against_the_oracle():
+    """a raw call of several pieces (the text travels with the table's pieces, the lines are hashed on a stream of their own ahead of the
+    window sums): 700 001 lines of 1..40 bytes with the table in the text's order (every line on the device when its piece is hashed),
+    reversed and shuffled (flag [1] of k_raw_scalars: the library repeats the call with the whole text first) - every line's two hashes
+    against the ORACLE's for the SHA-256 of that line (orc.mul_hash160_many), the all-ones filter letting every line through; then the
+    same through a filter that lets 3 in 1000 through, against the oracle's blf_has on those hashes"""
+    import ctypes as C
+    import hashlib
+    from ecloop_amd import Device, capi
+    rng = np.random.default_rng(2026)
+    n = 700_001
+    ln = rng.integers(1, 41, n).astype(np.uint64)
+    starts = np.concatenate([[0], np.cumsum(ln + 1)[:-1]]).astype(np.uint64)
+    tot = int(ln.sum()) + n
+    text = rng.integers(32, 127, tot, dtype=np.uint8)
+    text[(starts + ln).astype(np.int64)] = 10
+    blob = text.tobytes()
+    ks = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        dg = hashlib.sha256(blob[int(starts[i]): int(starts[i] + ln[i])]).digest()
+        ks[i] = np.frombuffer(dg, dtype=">u8")[::-1]
+    h33, h65, ok = orc.mul_hash160_many(ks, a33=True, a65=True)
+    assert ok.all()
+    in_order = starts | (ln << np.uint64(32))
+    words = synth_bloom_words(4099, 5, "a|b")  # bit density 0.75: 20 probes let 3 in 1000 through
+    flt = orc.OrcFilter(bloom_words=words)
+    passes = sorted((i, c) for c, hh in ((1, h33), (0, h65)) for i, row in enumerate(hh.tolist()) if flt.check(row))
+    d = Device(0, a33=True, a65=True)
+    try:
+        out = np.zeros(2 * n, dtype=capi.FOUND_DTYPE)
+        cnt = C.c_uint32()
+        for name, perm in (("text order", np.arange(n)), ("reversed", np.arange(n)[::-1].copy()), ("shuffled", rng.permutation(n))):
+            table = np.ascontiguousarray(in_order[perm])
+            d.set_bloom(ONES)
+            assert d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, tot, table.ctypes.data, n, out.ctypes.data, 2 * n, C.byref(cnt)) == 0, name
+            assert cnt.value == 2 * n, name
+            got = out[: 2 * n]
+            line = perm[got["key_offset"].astype(np.int64)]
+            comp = got["compressed"].astype(bool)
+            assert np.array_equal(got["h160"][comp], h33[line[comp]]) and np.array_equal(got["h160"][~comp], h65[line[~comp]]), name
+            assert comp.sum() == n and len(set(line[comp].tolist())) == n, name
+            d.set_bloom(words)
+            rc = d.lib.ecl_hip_mul_batch_raw(d.h, text.ctypes.data, tot, table.ctypes.data, n, out.ctypes.data, 2 * n, C.byref(cnt))
+            assert rc == 0, name
+            got = out[: cnt.value]
+            seen = sorted((int(perm[int(r["key_offset"])]), int(r["compressed"])) for r in got)
+            assert seen == passes and len(seen) > 1000, name
+    finally:
+        d.close()
+
+
 def test_sort_list_on_the_device_equals_qsort_by_compare_160():
     """ecl_hip_sort_list: load_filter's qsort by compare_160 (main.c:112, addr.c:18-26: word by word, unsigned) + duplicate
     removal, on the device; entries that differ only in the last / only in the first word, runs of duplicates, and the

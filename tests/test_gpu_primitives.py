@@ -152,7 +152,7 @@ def test_c_abi_error_codes():
         assert lib.ecl_hip_reserve_mul(h, 0, 16) == -1 and lib.ecl_hip_reserve_mul(None, 16, 16) == -1
         text = np.frombuffer(b"abcdef", dtype=np.uint8)
         table = np.array([0 | (6 << 32)], dtype=np.uint64)
-        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, (1 << 22) + 1, out.ctypes.data, 16, C.byref(n)) == -1
+        assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, (1 << 26) + 1, out.ctypes.data, 16, C.byref(n)) == -1
         assert lib.ecl_hip_mul_batch_raw(h, None, 6, table.ctypes.data, 1, out.ctypes.data, 16, C.byref(n)) == -1
         assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, None, 1, out.ctypes.data, 16, C.byref(n)) == -1
         assert lib.ecl_hip_mul_batch_raw(h, text.ctypes.data, 6, table.ctypes.data, 0, out.ctypes.data, 16, C.byref(n)) == 0 and n.value == 0
