@@ -961,8 +961,11 @@ def leg_mul(args, dev_index, words, blf, tmp, planted):
     ks.dev.reset_timing()
     device_fence(dev_index)
     t0 = time.perf_counter()
+    each = []
     for _ in range(args.cfg4_steps):
+        t1 = time.perf_counter()
         step()
+        each.append(round((time.perf_counter() - t1) * 1e3, 3))  # (a call returns when its records are on the host: the steps do not overlap)
     device_fence(dev_index)
     dt = time.perf_counter() - t0
     ms, calls, nsc = ks.dev.mul_timing()
@@ -1013,7 +1016,7 @@ def leg_mul(args, dev_index, words, blf, tmp, planted):
     api = {"metric": "M scalars/sec (mul -a cu, ecl_hip_mul_batch)", "value": round(n * args.cfg4_steps / dt / 1e6, 2), "unit": "Mscalars/s",
            "steps": args.cfg4_steps, "ms_per_step": round(dt / args.cfg4_steps * 1e3, 3),
            "config": {"workload": f"2^{args.cfg4_log2} seeded 256-bit scalars per call from page-locked HOST memory (copies overlapped with the kernels inside the call), "
-                                  "-a cu, 56 MB .blf at the design density", "window_bits": wbits, "first_call_ms_incl_table_build": round(t_first * 1e3, 1),
+                                  "-a cu, 56 MB .blf at the design density", "window_bits": wbits, "first_call_ms_incl_table_build": round(t_first * 1e3, 1), "steps_ms": each,
                       "hits_per_call": int(cnt.value), "pcie_gbs": round(drate * 32 / 1e9, 2),
                       "oracle_sample": f"the first {nsample} scalars (with {len(planted)} planted) through the oracle's cmd_mul: {len(cpu_lines)} lines, equal",
                       "found_list_matches_oracle_on_sample": True},
@@ -1094,7 +1097,62 @@ def leg_mul(args, dev_index, words, blf, tmp, planted):
                                      "rate = the host program's status line (clock from the end of bring-up to the last device call), median of 3 runs after one untimed pass",
                          "found": med[3], "wall_s_incl_process_start": round(med[2], 2),
                          "oracle_sample": f"the first {nsample} lines through the oracle's cmd_mul: {nwant} lines, equal (file and pipe runs)", "found_list_matches_oracle_on_sample": True}}
-    return {"api": api, "host_program": clileg}
+    # (c) the same program with -raw (main.c:503-527: the scalar of a line is its SHA-256 - pass phrases): hashed on the device, the text
+    # and the line table travel with the pieces of a call (ecl_hip_mul_batch_raw)
+    rawleg = leg_mul_raw(dev_index, cli, log2, tmp, shm, nsample)
+    return {"api": api, "host_program": clileg, "host_program_raw": rawleg}
+
+
+def leg_mul_raw(dev_index, cli, log2, tmp, shm, nsample):
+    import hashlib
+    orc = _orc()
+    nl = 1 << log2
+    gen = os.path.join(tmp, "gen_phrases")
+    subprocess.run(["gcc", "-O2", "-pthread", os.path.join(ROOT, "tools", "gen_phrases.c"), "-o", gen], check=True)
+    src = os.path.join(shm, "ecl_bench_mul_raw_%d.txt" % os.getpid())
+    import atexit
+    atexit.register(lambda: os.path.exists(src) and os.unlink(src))
+    t0 = time.perf_counter()
+    subprocess.run([gen, str(nl), "11", src, str(min(32, os.cpu_count() or 1))], check=True, stdout=subprocess.DEVNULL)
+    t_gen = time.perf_counter() - t0
+    with open(src, "rb") as f:
+        head = f.read(26 * nsample).split(b"\n")[:nsample]
+    scal = [int.from_bytes(hashlib.sha256(l).digest(), "big") for l in head]
+    planted = [scal[17 * i + 5] for i in range(16)]  # the filter holds the public keys of 16 of the first lines
+    words, blf, _ = secondary_filter(dev_index, planted, name="raw")
+    outp = os.path.join(tmp, "mul_raw_out.txt")
+
+    def run_cli():
+        if os.path.exists(outp):
+            os.unlink(outp)
+        t0 = time.perf_counter()
+        pr = subprocess.run([cli, "mul", "-raw", "-f", blf, "-a", "cu", "-q", "-o", outp], stdin=open(src, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        wall = time.perf_counter() - t0
+        if pr.returncode != 0:
+            raise SystemExit(f"[bench] cfg4: ecloop-hip mul -raw failed: {pr.stderr.decode(errors='replace')[-500:]}")
+        secs, mk, found, checked = _status_of(pr.stderr)
+        if checked != nl:
+            raise SystemExit(f"[bench] cfg4: ecloop-hip mul -raw checked {checked} of {nl} lines")
+        return mk, secs, wall, found
+
+    run_cli()
+    runs = [run_cli() for _ in range(3)]
+    first = set(scal)
+    mine = sorted(l.rstrip("\n") for l in open(outp) if int(l.split("\t")[2], 16) in first)
+    rc, o, no = orc.mul_batch(orc.OrcFilter(bloom_words=words), scal, a33=True, a65=True)
+    want = sorted(orc.found_lines(o, no))
+    if rc != 0 or mine != want or len(want) < 2 * len(planted):
+        raise SystemExit(f"[bench] cfg4: FOUND LIST MISMATCH of `mul -raw` on the oracle sample: {len(mine)} lines, oracle {len(want)}")
+    os.unlink(src)
+    rates = sorted(r[0] for r in runs)
+    med = runs[[r[0] for r in runs].index(rates[1])]
+    return {"metric": "M lines/sec (ecloop-hip mul -raw -a cu, pass phrases on stdin)", "value": med[0], "unit": "Mlines/s", "seconds_by_status_line": med[1],
+            "runs_mlines_s": [r[0] for r in runs], "spread": round((rates[2] - rates[0]) / rates[1], 4),
+            "config": {"workload": f"2^{log2} lines of 8..24 characters (tools/gen_phrases.c, {t_gen:.0f} s to write) from a regular file on stdin, SHA-256 of every line on the "
+                                   "device, -a cu, 56 MB .blf at the design density; rate = the host program's status line, median of 3 runs after one untimed pass",
+                       "found": med[3], "wall_s_incl_process_start": round(med[2], 2),
+                       "oracle_sample": f"the SHA-256 of the first {nsample} lines (16 of them planted in the filter) through the oracle's cmd_mul: {len(want)} lines, equal",
+                       "found_list_matches_oracle_on_sample": True}}
 
 
 def secondary_legs(args, dev_index):

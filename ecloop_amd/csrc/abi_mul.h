@@ -381,11 +381,12 @@ extern "C" int ecl_hip_mul_batch(ecl_hip* h, const uint64_t (*scalars)[4], uint3
   return rc;
 }
 
-// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests (n <= 2^26 lines a call).  The text crosses PCIe
-// first, whole (a line may lie anywhere in it); the line table follows piece by piece on the copy stream, and every piece hashes its lines
-// into its staging buffer in front of its window sums, on the piece's compute stream - the pieces of ecl_hip_mul_batch, with 8 bytes of
-// table + the line instead of 32 bytes of scalar.  (Until round 6 a call was ONE piece of at most 2^22 lines on one stream, and the host
-// program made ~2 M-line calls: 0.79-0.87 G lines/s over 2^30 pass phrases against 1.25 for hex lines.)
+// `mul -raw`: lines of text in, SHA-256 on the device, then the `mul` body on the digests (n <= 2^26 lines a call): the pieces of
+// ecl_hip_mul_batch, with 8 bytes of table + the line instead of 32 bytes of scalar on the copy stream, and every piece's lines hashed
+// into its staging buffer ahead of its window sums (details at the two lambdas below).  Until round 6 a call was ONE piece of at most
+// 2^22 lines on one stream and the host program made ~2 M-line calls: 0.79-0.87 G lines/s over 2^30 pass phrases; as pieces with the
+// hashing between the window sums of one stream and the whole text sent first, 2^24-line calls took 20.2 ms against 14.0 for 2^24
+// scalars; now 14.5-15.1 ms (tools/raw_api_probe.py), 1.09-1.16 G lines/s through the host program (tools/rawprobe3_r06.sh).
 extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t text_bytes, const uint64_t* lines, uint32_t n, ecl_found* out,
                                      uint32_t cap, uint32_t* nout) {
   if (!h || (!text && text_bytes) || (!lines && n) || (!out && cap) || !nout || n > MUL_RAW_MAX || text_bytes > 0xFFFFFFF0u || cap > ECL_CAP_MAX) return ECL_E_ARG;
@@ -430,8 +431,7 @@ extern "C" int ecl_hip_mul_batch_raw(ecl_hip* h, const uint8_t* text, uint32_t t
   if (!h->prep_stream) {
     int lo = 0, hi = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (numerically lower = higher priority)
-    static const u32 prio = env_u32("ECL_HIP_RAW_PRIORITY", 1u, 0u, 1u);  // A/B hook
-    HIPCHK(h, hipStreamCreateWithPriority(&h->prep_stream, hipStreamNonBlocking, prio ? hi : lo));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->prep_stream, hipStreamNonBlocking, hi));  // (lowest priority instead: no difference measured)
     for (int i = 0; i < MUL_NBUF; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_hashed[i], hipEventDisableTiming));
   }
   add_args a;

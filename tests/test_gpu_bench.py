@@ -60,6 +60,8 @@ def test_bench_secondary_legs_at_reduced_size():
     assert abs(api["value"] - (1 << 22) / (api["ms_per_step"] * 1e3)) / api["value"] < 1e-3
     assert cli["config"]["found_list_matches_oracle_on_sample"] and cli["value"] > 10
     assert len(cli["runs_mlines_s"]) == 3 and cli["value"] == sorted(cli["runs_mlines_s"])[1] and cli["pipe"]["value"] > 1 and cli["pipe"]["lines_log2"] == 22
+    raw = s["cfg4"]["host_program_raw"]  # pass phrases, hashed on the device
+    assert raw["config"]["found_list_matches_oracle_on_sample"] and raw["value"] > 10 and raw["value"] == sorted(raw["runs_mlines_s"])[1]
     # the reference's 2^21-key hand-out through the host program: found lists equal, the look-ahead ahead of plain launches
     sj = s["small_jobs"]
     assert sj["config"]["found_lists_equal_to_the_large_call_run"] and sj["value"] > sj["lookahead_off"] > 1000 and sj["eight_worker_threads_on_eight_contexts"] > 1000
