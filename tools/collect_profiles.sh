@@ -148,6 +148,8 @@ if want binding; then
 fi
 if want mulcli; then
   bash tools/bench_mul_cli.sh 30 3 > "$O/mul_cli.txt" 2>&1
+  { echo "# tools/bench_mul_raw.sh 1073741824: mul -raw over 2^30 pass phrases of 8..24 characters (tools/gen_phrases.c), one untimed pass first"
+    bash tools/bench_mul_raw.sh 1073741824; } >> "$O/mul_cli.txt" 2>&1
   cp "$O/mul_cli.txt" "profiles/${TAG}_mul_cli.txt"; grep -E "^#|run [0-9]|parse only" "profiles/${TAG}_mul_cli.txt" | cut -c1-200
 fi
 # bit-exact found lists against the reference binary on the final build: the whole 2^32-key range of the headline config (54 MB filter)
