@@ -154,6 +154,26 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) static bool hex64_avx512(co
   _mm256_storeu_si256((__m256i *)dst, _mm256_permute2x128_si256(rev, rev, 1)); /* all 32 bytes reversed: least significant limb first */
   return true;
 }
+/* a line of 1..64 hex digits (most significant first, any length: "1f", 40 digits, 64) -> the value's four little-endian u64 at dst; false
+   if any character is not a hex digit (the caller's scalar loop then applies fe_modn_from_hex's skipping).  The line is loaded right-
+   aligned - the 64 bytes that END at the line's end, the bytes in front of the line masked off and read as '0' (a masked load does not
+   touch what it masks, so the line may start a buffer) - and decoded like a whole record. */
+__attribute__((target("avx512f,avx512bw,avx512vl"))) static bool hexline_avx512(const char *p, size_t len, u64 *dst) {
+  const __mmask64 m = ~(__mmask64)0 << (64 - len);
+  const __m512i c = _mm512_mask_loadu_epi8(_mm512_set1_epi8('0'), m, (const void *)(p + len - 64));
+  const __m512i lower = _mm512_or_si512(c, _mm512_set1_epi8(0x20));
+  const __mmask64 isdig = _mm512_cmpgt_epi8_mask(c, _mm512_set1_epi8('0' - 1)) & _mm512_cmplt_epi8_mask(c, _mm512_set1_epi8('9' + 1));
+  const __mmask64 isalp = _mm512_cmpgt_epi8_mask(lower, _mm512_set1_epi8('a' - 1)) & _mm512_cmplt_epi8_mask(lower, _mm512_set1_epi8('f' + 1));
+  if ((isdig | isalp) != ~(__mmask64)0) return false;
+  const __m512i low = _mm512_and_si512(c, _mm512_set1_epi8(0x0F));
+  const __m512i nib = _mm512_mask_add_epi8(low, isalp, low, _mm512_set1_epi8(9));
+  const __m512i pair = _mm512_maddubs_epi16(nib, _mm512_set1_epi16(0x0110));
+  const __m256i bytes = _mm512_cvtepi16_epi8(pair);
+  const __m256i rev = _mm256_shuffle_epi8(bytes, _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4,
+                                                                  3, 2, 1, 0));
+  _mm256_storeu_si256((__m256i *)dst, _mm256_permute2x128_si256(rev, rev, 1));
+  return true;
+}
 #endif
 static bool have_ssse3, have_avx2, have_avx512; /* set once in main */
 

@@ -160,6 +160,8 @@ static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, co
 static sc line_to_scalar(const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
 #if defined(__x86_64__)
+  if (have_avx512 && len && len <= 64 && hexline_avx512(p, len, k.w)) return len == 64 ? sc_reduce(k) : k; /* (fewer than 64 digits: below n) */
+  k = (sc){{0, 0, 0, 0}};
   if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
       hex16_ssse3(p + 48, &k.w[0]))
     return sc_reduce(k);

@@ -9,7 +9,7 @@ for f in mul_odd mul_in mul_var; do
   $CLI mul -f $ROOT/tests/golden/btc-bw-hash -a cu -q -o /tmp/o.txt < /dev/shm/$f.txt >/dev/null 2>&1
   for rep in 1 2 3; do
     t0=$(date +%s.%N); ECLOOP_HIP_STATS=1 $CLI mul -f $ROOT/tests/golden/btc-bw-hash -a cu -q -o /tmp/o.txt < /dev/shm/$f.txt 2>/tmp/e.txt >/tmp/s.txt; t1=$(date +%s.%N)
-    echo "$f 2^$L lines run $rep: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s | status: $(tr '\r' '\n' < /tmp/e.txt | grep Mkeys | tail -1) | $(tr '\r' '\n' < /tmp/e.txt | grep 'front end' | cut -c1-120)"
+    echo "$f 2^$L lines run $rep: wall $(python3 -c "print('%.2f' % ($t1 - $t0))") s | status: $(tr '\r' '\n' < /tmp/e.txt | grep Mkeys | tail -1) | $(tr '\r' '\n' < /tmp/e.txt | grep 'front end' | cut -c1-400)"
   done
 done
 rm -f /dev/shm/mul_in.txt /dev/shm/mul_odd.txt /dev/shm/mul_var.txt
