@@ -479,11 +479,12 @@ static void *mul_reader(void *arg) {
   }
   q->input_done = true; /* whatever follows reads to the end of the input */
 #ifdef F_SETPIPE_SZ
-  { /* a pipe on stdin (`cat keys | ecloop-hip mul`): more than the default 64 KB in flight - fewer wake-ups of the writer.  64 MB where the
-       process may (above /proc/sys/fs/pipe-max-size takes CAP_SYS_RESOURCE), else 1 MB: 8.7 GB of lines through `cat |` on 8 cores 1.0 GB/s
-       at 64 KB, 2.1 at 1 MB, 2.4 at 16 MB, 2.6 at 64 MB */
+  { /* a pipe on stdin (`cat keys | ecloop-hip mul`): 1 MB instead of the default 64 KB in flight - fewer wake-ups of the writer.  More does not
+       pay where it matters (tools/pipeprobe_r06.sh on the GPU box, 2^28 hex lines: 91-101 M lines/s at 1 MB, 98-101 at 16 MB, 100-103 at
+       64 MB; -raw 330-410 M pass phrases/s at every size: `cat` is at its rate), though it did on the 8-core build container (2.1 / 2.4 /
+       2.6 GB/s).  Above /proc/sys/fs/pipe-max-size the call needs CAP_SYS_RESOURCE. */
     const char *e = getenv("ECLOOP_HIP_PIPE_SZ"); /* experiments */
-    long want = e && atol(e) >= 4096 ? atol(e) : 64l << 20;
+    long want = e && atol(e) >= 4096 ? atol(e) : 1l << 20;
     while (want >= (1l << 20) && fcntl(0, F_SETPIPE_SZ, (int)want) < 0) want >>= 2;
   }
 #endif
