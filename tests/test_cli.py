@@ -644,6 +644,32 @@ def test_mul_parser_raw_and_bin_and_chunk_boundaries(cli):
         assert int(out[i], 16) == (v - N if v >= N else v), i
 
 
+def test_mul_parser_raw_file_in_chunks_of_a_forced_size(cli, tmp_path):
+    """`mul -raw` from a regular file (cli_mul.h: the mapped file in chunks of mul_raw_chunk() bytes cut at line ends, P threads list the
+    lines, a second pass packs the table): 200 000 pass phrases of 0..60 characters, an empty line and a CR LF line among them, the last
+    line without newline, with the chunk size forced to 64 KB / 1 MB (dozens of chunks, lines that straddle the cut) - the digests the
+    device would compute from the line table (hidden `parse` command) against hashlib; the same bytes through a pipe give the same"""
+    import hashlib
+    import random
+    r = random.Random(21)
+    abc = "abcdefghijklmnopqrstuvwxyz0123456789 -_"
+    lines = ["".join(r.choice(abc) for _ in range(r.randrange(0, 61))) for _ in range(200_000)]
+    lines[5], lines[77] = "", "with carriage return\r"
+    blob = ("\n".join(lines)).encode()  # (no newline at the end)
+    want = [hashlib.sha256(l.rstrip("\r").encode()).hexdigest() for l in lines if l.rstrip("\r")]
+    src = tmp_path / "phrases.txt"
+    src.write_bytes(blob)
+    for chunk in ("65536", "1048576", None):
+        env = dict(os.environ, ECLOOP_HIP_STATS="1")
+        if chunk:
+            env["ECLOOP_HIP_MUL_RAW_CHUNK"] = chunk
+        pr = subprocess.run([cli, "parse", "-raw"], stdin=open(src, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, timeout=300, env=env)
+        assert pr.stdout.decode().split() == want, chunk
+        m = re.search(r"(\d+) chunks", pr.stderr.decode())
+        assert m and (int(m.group(1)) >= len(blob) // int(chunk) if chunk else int(m.group(1)) == 1), pr.stderr.decode()[-300:]
+    assert _parse(cli, blob, "-raw") == want
+
+
 @pytest.mark.parametrize("decoder", ["avx512", "avx2", "ssse3"])
 def test_mul_parser_file_of_64_digit_lines_in_batches(cli, tmp_path, decoder):
     """a regular file of 64-digit lines on stdin is taken in batches straight from the file (cli_mul.h: pread slices, one decoder per
