@@ -885,124 +885,124 @@ static void cmd_mul(run_t *run) {
   char *last_map = NULL;
   size_t last_map_size = 0;
   for (;;) {
-  size_t limit = 0;
-  {
-    off_t pos;
-    size_t rec;
-    struct stat stt;
-    const size_t total = mul_fixed_file_records(run, &pos, &rec);
-    const bool file = pos >= 0 && fstat(0, &stt) == 0 && S_ISREG(stt.st_mode);
-    if (total) {
-      const size_t done = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
-      nbatch_records += done;
-      if (pos + (off_t)(done * rec) >= stt.st_size) break; /* the whole file */
-      if (done < total) { /* stopped at a batch that is not all records */
-        const size_t batch = mul_batch_records(total);
-        limit = (total - done < batch ? total - done : batch) * rec;
+    size_t limit = 0;
+    {
+      off_t pos;
+      size_t rec;
+      struct stat stt;
+      const size_t total = mul_fixed_file_records(run, &pos, &rec);
+      const bool file = pos >= 0 && fstat(0, &stt) == 0 && S_ISREG(stt.st_mode);
+      if (total) {
+        const size_t done = mul_fixed_file_run(run, &pool, P, &sq, pos, total, rec, &t_array, &t_grow, &t_parse, &nbatches);
+        nbatch_records += done;
+        if (pos + (off_t)(done * rec) >= stt.st_size) break; /* the whole file */
+        if (done < total) { /* stopped at a batch that is not all records */
+          const size_t batch = mul_batch_records(total);
+          limit = (total - done < batch ? total - done : batch) * rec;
+        }
+        misses = 0;
+      } else if (file && !run->opt.raw && !run->bin) {
+        if (stt.st_size <= pos) break;
+        /* a header costs 1 MB at the general reader's rate; a file with no records to find doubles the stretch each time, and after 8 looks
+           (256 MB) the general reader keeps the rest (limit 0), which is what it did before there were stretches */
+        limit = misses < 8 ? first_stretch << misses : 0;
+        misses++;
       }
-      misses = 0;
-    } else if (file && !run->opt.raw && !run->bin) {
-      if (stt.st_size <= pos) break;
-      /* a header costs 1 MB at the general reader's rate; a file with no records to find doubles the stretch each time, and after 8 looks
-         (256 MB) the general reader keeps the rest (limit 0), which is what it did before there were stretches */
-      limit = misses < 8 ? first_stretch << misses : 0;
-      misses++;
     }
-  }
-  pthread_mutex_lock(&tq.mu);
-  tq.head = tq.tail = tq.count = 0, tq.eof = tq.input_done = false, tq.limit = limit, tq.map = NULL, tq.map_size = 0;
-  pthread_mutex_unlock(&tq.mu);
-  tq.chunk = mul_general_chunk(run);
-  pthread_create(&reader, NULL, mul_reader, &tq);
-  for (;;) {
-    t_mark = us_now();
     pthread_mutex_lock(&tq.mu);
-    while (!tq.count && !tq.eof) pthread_cond_wait(&tq.cv, &tq.mu);
-    if (!tq.count) { pthread_mutex_unlock(&tq.mu); break; }
-    text_chunk *c = &tq.ring[tq.tail];
+    tq.head = tq.tail = tq.count = 0, tq.eof = tq.input_done = false, tq.limit = limit, tq.map = NULL, tq.map_size = 0;
     pthread_mutex_unlock(&tq.mu);
-    t_text += us_now() - t_mark, t_mark = us_now(), nchunks++;
-    /* an array for this chunk's scalars */
-    pthread_mutex_lock(&sq.mu);
-    while (!sq.nidle) pthread_cond_wait(&sq.cv, &sq.mu);
-    int ai = sq.idle[--sq.nidle];
-    pthread_mutex_unlock(&sq.mu);
-    t_array += us_now() - t_mark, t_mark = us_now();
-    scalar_array *ar = &sq.arr[ai];
-    if (run->bin) { /* the scalars as they are: into the page-locked array, P threads copying */
-      ar->n = c->len / 32;
-      ks_grow(run, ar, ar->n);
-      t_grow += us_now() - t_mark, t_mark = us_now();
-      copy_task ct[MUL_POOL_MAX];
-      size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
-      int nc = 0;
-      for (size_t at = 0; at < ar->n; at += per, ++nc)
-        ct[nc] = (copy_task){ar->ks + at, c->buf + at * 32, (ar->n - at < per ? ar->n - at : per) * 32};
-      pool_run(&pool, copy_worker, ct, sizeof ct[0], nc);
-      t_parse += us_now() - t_mark;
-    } else if (run->opt.raw) { /* text and line table for the GPU */
-      raw_grow(run, ar, c->len, 0);
-      t_grow += us_now() - t_mark, t_mark = us_now();
-      int ns = 0;
-      size_t at = 0, end = c->len;
-      for (int i = 0; i < P && at < end; ++i) {
-        size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
-        if (stop <= at) stop = at + 1;
-        while (stop < end && c->buf[stop - 1] != '\n') stop++;
-        rs[ns].buf = c->buf, rs[ns].text_dst = ar->text, rs[ns].beg = at, rs[ns].end = stop;
-        at = stop, ns++;
+    tq.chunk = mul_general_chunk(run);
+    pthread_create(&reader, NULL, mul_reader, &tq);
+    for (;;) {
+      t_mark = us_now();
+      pthread_mutex_lock(&tq.mu);
+      while (!tq.count && !tq.eof) pthread_cond_wait(&tq.cv, &tq.mu);
+      if (!tq.count) { pthread_mutex_unlock(&tq.mu); break; }
+      text_chunk *c = &tq.ring[tq.tail];
+      pthread_mutex_unlock(&tq.mu);
+      t_text += us_now() - t_mark, t_mark = us_now(), nchunks++;
+      /* an array for this chunk's scalars */
+      pthread_mutex_lock(&sq.mu);
+      while (!sq.nidle) pthread_cond_wait(&sq.cv, &sq.mu);
+      int ai = sq.idle[--sq.nidle];
+      pthread_mutex_unlock(&sq.mu);
+      t_array += us_now() - t_mark, t_mark = us_now();
+      scalar_array *ar = &sq.arr[ai];
+      if (run->bin) { /* the scalars as they are: into the page-locked array, P threads copying */
+        ar->n = c->len / 32;
+        ks_grow(run, ar, ar->n);
+        t_grow += us_now() - t_mark, t_mark = us_now();
+        copy_task ct[MUL_POOL_MAX];
+        size_t per = (ar->n + (size_t)P - 1) / (size_t)P;
+        int nc = 0;
+        for (size_t at = 0; at < ar->n; at += per, ++nc)
+          ct[nc] = (copy_task){ar->ks + at, c->buf + at * 32, (ar->n - at < per ? ar->n - at : per) * 32};
+        pool_run(&pool, copy_worker, ct, sizeof ct[0], nc);
+        t_parse += us_now() - t_mark;
+      } else if (run->opt.raw) { /* text and line table for the GPU */
+        raw_grow(run, ar, c->len, 0);
+        t_grow += us_now() - t_mark, t_mark = us_now();
+        int ns = 0;
+        size_t at = 0, end = c->len;
+        for (int i = 0; i < P && at < end; ++i) {
+          size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
+          if (stop <= at) stop = at + 1;
+          while (stop < end && c->buf[stop - 1] != '\n') stop++;
+          rs[ns].buf = c->buf, rs[ns].text_dst = ar->text, rs[ns].beg = at, rs[ns].end = stop;
+          at = stop, ns++;
+        }
+        pool_run(&pool, raw_scan_worker, rs, sizeof rs[0], ns);
+        t_parse += us_now() - t_mark, t_mark = us_now();
+        size_t total = 0;
+        for (int i = 0; i < ns; ++i) total += rs[i].count;
+        raw_grow(run, ar, c->len, total);
+        t_grow += us_now() - t_mark, t_mark = us_now();
+        ar->n = total, ar->text_len = c->len;
+        size_t off = 0;
+        for (int i = 0; i < ns; ++i) rs[i].dst = ar->lines + off, off += rs[i].count;
+        pool_run(&pool, raw_pack_worker, rs, sizeof rs[0], ns);
+        t_pack += us_now() - t_mark;
+      } else if (parse_fixed_chunk(run, &pool, P, c, ar, &t_grow, &t_parse, &t_mark)) {
+        nfixed++; /* every line was 64 hex digits + newline: parsed in place */
+      } else {
+        int ns = 0;
+        size_t at = 0, end = c->len;
+        for (int i = 0; i < P && at < end; ++i) { /* slices at line boundaries */
+          size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
+          if (stop <= at) stop = at + 1;
+          while (stop < end && c->buf[stop - 1] != '\n') stop++;
+          sl[ns].run = run, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
+          at = stop, ns++;
+        }
+        pool_run(&pool, parse_worker, sl, sizeof sl[0], ns);
+        t_parse += us_now() - t_mark, t_mark = us_now();
+        size_t total = 0;
+        for (int i = 0; i < ns; ++i) total += sl[i].count;
+        ks_grow(run, ar, total);
+        t_grow += us_now() - t_mark, t_mark = us_now();
+        ar->n = total;
+        size_t off = 0;
+        for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count;
+        pool_run(&pool, pack_worker, sl, sizeof sl[0], ns);
+        t_pack += us_now() - t_mark;
       }
-      pool_run(&pool, raw_scan_worker, rs, sizeof rs[0], ns);
-      t_parse += us_now() - t_mark, t_mark = us_now();
-      size_t total = 0;
-      for (int i = 0; i < ns; ++i) total += rs[i].count;
-      raw_grow(run, ar, c->len, total);
-      t_grow += us_now() - t_mark, t_mark = us_now();
-      ar->n = total, ar->text_len = c->len;
-      size_t off = 0;
-      for (int i = 0; i < ns; ++i) rs[i].dst = ar->lines + off, off += rs[i].count;
-      pool_run(&pool, raw_pack_worker, rs, sizeof rs[0], ns);
-      t_pack += us_now() - t_mark;
-    } else if (parse_fixed_chunk(run, &pool, P, c, ar, &t_grow, &t_parse, &t_mark)) {
-      nfixed++; /* every line was 64 hex digits + newline: parsed in place */
-    } else {
-      int ns = 0;
-      size_t at = 0, end = c->len;
-      for (int i = 0; i < P && at < end; ++i) { /* slices at line boundaries */
-        size_t stop = i == P - 1 ? end : at + (end - at) / (size_t)(P - i);
-        if (stop <= at) stop = at + 1;
-        while (stop < end && c->buf[stop - 1] != '\n') stop++;
-        sl[ns].run = run, sl[ns].buf = c->buf, sl[ns].beg = at, sl[ns].end = stop;
-        at = stop, ns++;
-      }
-      pool_run(&pool, parse_worker, sl, sizeof sl[0], ns);
-      t_parse += us_now() - t_mark, t_mark = us_now();
-      size_t total = 0;
-      for (int i = 0; i < ns; ++i) total += sl[i].count;
-      ks_grow(run, ar, total);
-      t_grow += us_now() - t_mark, t_mark = us_now();
-      ar->n = total;
-      size_t off = 0;
-      for (int i = 0; i < ns; ++i) sl[i].dst = ar->ks + off, off += sl[i].count;
-      pool_run(&pool, pack_worker, sl, sizeof sl[0], ns);
-      t_pack += us_now() - t_mark;
+      pthread_mutex_lock(&tq.mu); /* the text buffer goes back to the reader */
+      tq.tail = (tq.tail + 1) % MUL_TEXT_RING, tq.count--;
+      pthread_cond_broadcast(&tq.cv);
+      pthread_mutex_unlock(&tq.mu);
+      pthread_mutex_lock(&sq.mu);
+      sq.ready[sq.nready++] = ai;
+      pthread_cond_broadcast(&sq.cv);
+      pthread_mutex_unlock(&sq.mu);
     }
-    pthread_mutex_lock(&tq.mu); /* the text buffer goes back to the reader */
-    tq.tail = (tq.tail + 1) % MUL_TEXT_RING, tq.count--;
-    pthread_cond_broadcast(&tq.cv);
-    pthread_mutex_unlock(&tq.mu);
-    pthread_mutex_lock(&sq.mu);
-    sq.ready[sq.nready++] = ai;
-    pthread_cond_broadcast(&sq.cv);
-    pthread_mutex_unlock(&sq.mu);
-  }
-  pthread_join(reader, NULL);
-  /* every chunk of the stretch has been parsed into an array.  The LAST mapping is left alone until the devices are done: munmap of 18 GB
-     of touched pages holds the process's address-space lock for 0.2 s, and the device threads' launches and copies stood still behind it
-     (rocprofv3 --hip-runtime-trace: one hipLaunchKernel of 220 ms and one hipMemcpyAsync of 217 ms, both threads at once - a fifth of
-     a 2^30-line -raw run) */
-  if (tq.input_done) { last_map = tq.map, last_map_size = tq.map_size; break; }
-  if (tq.map) munmap(tq.map, tq.map_size);
+    pthread_join(reader, NULL);
+    /* every chunk of the stretch has been parsed into an array.  The LAST mapping is left alone until the devices are done: munmap of 18 GB
+       of touched pages holds the process's address-space lock for 0.2 s, and the device threads' launches and copies stood still behind it
+       (rocprofv3 --hip-runtime-trace: one hipLaunchKernel of 220 ms and one hipMemcpyAsync of 217 ms, both threads at once - a fifth of
+       a 2^30-line -raw run) */
+    if (tq.input_done) { last_map = tq.map, last_map_size = tq.map_size; break; }
+    if (tq.map) munmap(tq.map, tq.map_size);
   } /* stretches */
   pthread_mutex_lock(&sq.mu);
   sq.done = true;
