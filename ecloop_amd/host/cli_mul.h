@@ -409,11 +409,13 @@ static size_t mul_raw_lines_estimate(void) {
   struct stat st;
   const off_t pos = lseek(0, 0, SEEK_CUR);
   if (pos < 0 || fstat(0, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= pos) return 0;
-  static char head[256 << 10];
-  const ssize_t got = pread(0, head, sizeof head, pos);
-  if (got <= 0) return 0;
+  const size_t look = 256 << 10; /* (every context's bring-up thread asks: a buffer of its own) */
+  char *head = malloc(look);
+  const ssize_t got = head ? pread(0, head, look, pos) : 0;
   size_t nl = 0;
   for (ssize_t i = 0; i < got; ++i) nl += head[i] == '\n';
+  free(head);
+  if (got <= 0) return 0;
   if (!nl) nl = 1;
   return (size_t)((double)(st.st_size - pos) * (double)nl / (double)got);
 }
