@@ -160,7 +160,13 @@ static void mul_flush_raw(run_t *run, int g, const u8 *text, size_t text_len, co
 static sc line_to_scalar(const char *p, size_t len) {
   sc k = {{0, 0, 0, 0}};
 #if defined(__x86_64__)
-  if (have_avx512 && len && len <= 64 && hexline_avx512(p, len, k.w)) return len == 64 ? sc_reduce(k) : k; /* (fewer than 64 digits: below n) */
+  if (have_avx512 && len) {
+    /* "0x" in front of at most 64 digits changes nothing: read right to left, the x is skipped and the 0 is a leading zero or the 65th digit */
+    const bool prefixed = len >= 3 && len <= 66 && p[0] == '0' && (p[1] | 0x20) == 'x';
+    const char *q = prefixed ? p + 2 : p;
+    const size_t n = prefixed ? len - 2 : len;
+    if (n <= 64 && hexline_avx512(q, n, k.w)) return n == 64 ? sc_reduce(k) : k; /* (fewer than 64 digits: below n) */
+  }
   k = (sc){{0, 0, 0, 0}};
   if (len == 64 && have_ssse3 && hex16_ssse3(p, &k.w[3]) && hex16_ssse3(p + 16, &k.w[2]) && hex16_ssse3(p + 32, &k.w[1]) &&
       hex16_ssse3(p + 48, &k.w[0]))
