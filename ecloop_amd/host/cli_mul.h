@@ -683,7 +683,7 @@ static bool parse_fixed_chunk(const run_t *run, pool_t *pool, int P, const text_
    the input goes through the general reader below, which starts at the file offset this path leaves. */
 #define MUL_BATCH_LOG2 24
 #define MUL_SLICE_RECORDS_MAX 32768u
-typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; size_t rec; atomic_bool bad; } fixed_batch; /* rec: 65 (LF lines), 66 (CRLF), 32 (-bin) */
+typedef struct { int fd; const char *map; off_t base; u64 (*dst)[4]; size_t rec; atomic_bool bad; } fixed_batch; /* rec: 65 (LF lines), 66 (CRLF), 67 / 68 (the same behind "0x"), 32 (-bin) */
 static atomic_ullong fixed_read_us, fixed_decode_us; /* summed over the pool's threads (ECLOOP_HIP_STATS) */
 typedef struct { fixed_batch *b; size_t first, last; } fixed_file_slice;
 static bool pread_all(int fd, char *dst, size_t bytes, off_t at) {
@@ -712,17 +712,19 @@ static void *fixed_file_worker(void *arg) {
   if (b->map) src = b->map + at;
   else {
     static __thread char *mine; /* this thread's text buffer, for the life of the command */
-    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS_MAX * 66))) { atomic_store(&b->bad, true); return NULL; }
+    if (!mine && !(mine = malloc((size_t)MUL_SLICE_RECORDS_MAX * 68))) { atomic_store(&b->bad, true); return NULL; }
     if (!pread_all(b->fd, mine, bytes, at)) { atomic_store(&b->bad, true); return NULL; }
     src = mine;
   }
-  const bool wide = have_avx2, widest = have_avx512, crlf = rec == 66;
+  const bool wide = have_avx2, widest = have_avx512, crlf = rec == 66 || rec == 68, prefixed = rec >= 67;
   const u64 t1 = us_now();
   for (size_t r = 0; r < s->last - s->first; ++r) {
     const char *p = src + r * rec;
     u64 *dst = b->dst[s->first + r];
     sc k;
-    const bool ended = crlf ? p[64] == '\r' && p[65] == '\n' : p[64] == '\n';
+    bool ended = true;
+    if (prefixed) ended = p[0] == '0' && (p[1] | 0x20) == 'x', p += 2; /* (fe_modn_from_hex reads right to left: behind 64 digits nothing counts) */
+    ended = ended && (crlf ? p[64] == '\r' && p[65] == '\n' : p[64] == '\n');
     if (widest) { /* one load per record; the scalar goes straight to its slot, reduced there in the one case in 2^128 that needs it */
       if (ended && hex64_avx512(p, dst)) {
         if (dst[3] == ~0ull) memcpy(k.w, dst, 32), k = sc_reduce(k), memcpy(dst, k.w, 32);
@@ -750,15 +752,18 @@ static void *fixed_file_worker(void *arg) {
    -bin 32 (the scalars themselves); 0: not a regular file, -raw, no SSSE3, or the first line is not a 64-digit record */
 static size_t mul_fixed_file_records(const run_t *run, off_t *pos, size_t *rec) {
   struct stat stt;
-  char first[66];
+  char head[68], *first = head;
   *pos = lseek(0, 0, SEEK_CUR), *rec = MUL_RECORD;
   const char *how = getenv("ECLOOP_HIP_MUL_READ"); /* "chunks": the general reader only (tests compare the two) */
   if (how && !strcmp(how, "chunks")) return 0;
   if (run->opt.raw || *pos < 0 || fstat(0, &stt) != 0 || !S_ISREG(stt.st_mode) || stt.st_size < *pos + 66) return 0;
   if (run->bin) return *rec = 32, (size_t)(stt.st_size - *pos) / 32;
-  if (!have_ssse3 || pread(0, first, 66, *pos) != 66) return 0;
-  if (first[64] == '\r' && first[65] == '\n') *rec = 66;
-  else if (first[64] != '\n') return 0;
+  if (!have_ssse3 || stt.st_size < *pos + 68 || pread(0, head, 68, *pos) != 68) return 0;
+  size_t lead = 0;
+  if (first[0] == '0' && (first[1] | 0x20) == 'x') first += 2, lead = 2; /* keys written as 0x + 64 digits */
+  if (first[64] == '\r' && first[65] == '\n') *rec = lead + 66;
+  else if (first[64] == '\n') *rec = lead + 65;
+  else return 0;
   return (size_t)(stt.st_size - *pos) / *rec;
 }
 /* records per batch for a file of `total` records: 2^24 for large files (the device's rate needs calls that long); a smaller file is cut

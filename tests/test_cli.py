@@ -746,6 +746,19 @@ def test_mul_parser_crlf_files_and_binary_files_in_batches(cli, tmp_path):
     # 2 batches of LF records, the batch with the change of record length through the general reader, then CR LF records in batches again
     m = re.search(r"(\d+) batches of fixed records straight from the file \((\d+) lines\)", stats)
     assert got == ["%064x" % (v % N) for v in vals] and m and int(m.group(1)) >= 6 and int(m.group(2)) >= 24000, stats
+    # keys written as 0x + 64 digits (67-byte records, 68 with CR LF): the same path, two bytes further in; an upper-case X among them,
+    # and one line with the prefix missing stops the batch it is in
+    for name, end, batches in (("x.txt", b"\n", 8), ("xcrlf.txt", b"\r\n", 8)):
+        f = tmp_path / name
+        f.write_bytes(b"".join((b"0X" if i % 11 == 3 else b"0x") + b"%064x" % v + end for i, v in enumerate(vals)))
+        got, stats = parse(str(f))
+        assert got == ["%064x" % (v % N) for v in vals] and "%d batches of fixed records straight from the file (30000 lines)" % batches in stats, stats
+        assert parse(str(f), ECLOOP_HIP_MUL_READ="chunks")[0] == got
+    f = tmp_path / "xodd.txt"
+    f.write_bytes(b"".join((b"" if i == 20000 else b"0x") + b"%064x\n" % v for i, v in enumerate(vals)))
+    got, stats = parse(str(f))
+    m = re.search(r"(\d+) batches of fixed records straight from the file \((\d+) lines\)", stats)
+    assert got == ["%064x" % (v % N) for v in vals] and m and 20000 <= int(m.group(2)) < 30000, stats
     raw = tmp_path / "k.bin"
     raw.write_bytes(b"".join(v.to_bytes(32, "little") for v in vals) + b"\x01\x02\x03")
     got, stats = parse(str(raw), "-bin")
