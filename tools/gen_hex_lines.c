@@ -15,25 +15,27 @@ static inline uint64_t mix(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-typedef struct { int fd; uint64_t seed, first, last; } job_t;
+typedef struct { int fd; uint64_t seed, first, last; int lead; } job_t; /* lead: 2 = every line starts with "0x" (67-byte records) */
 static void *work(void *arg) {
   const job_t *j = arg;
   enum { BLOCK = 16384 };
   static const char hex[] = "0123456789abcdef";
-  char *buf = malloc((size_t)BLOCK * 65);
+  const size_t rec = 65 + (size_t)j->lead;
+  char *buf = malloc((size_t)BLOCK * rec);
   for (uint64_t at = j->first; at < j->last; at += BLOCK) {
     const uint64_t n = j->last - at < BLOCK ? j->last - at : BLOCK;
     for (uint64_t r = 0; r < n; ++r) {
-      char *p = buf + r * 65;
+      char *p = buf + r * rec;
+      if (j->lead) *p++ = '0', *p++ = 'x';
       for (int w = 0; w < 4; ++w) {
         const uint64_t v = mix(j->seed + ((at + r) * 4 + (uint64_t)w + 1) * 0x9E3779B97F4A7C15ull);
         for (int d = 0; d < 16; ++d) p[16 * w + d] = hex[(v >> (60 - 4 * d)) & 15];
       }
       p[64] = '\n';
     }
-    size_t off = 0, bytes = (size_t)n * 65;
+    size_t off = 0, bytes = (size_t)n * rec;
     while (off < bytes) {
-      ssize_t k = pwrite(j->fd, buf + off, bytes - off, (off_t)(at * 65 + off));
+      ssize_t k = pwrite(j->fd, buf + off, bytes - off, (off_t)(at * rec + off));
       if (k <= 0) { perror("pwrite"); exit(1); }
       off += (size_t)k;
     }
@@ -42,17 +44,18 @@ static void *work(void *arg) {
   return NULL;
 }
 int main(int argc, char **argv) {
-  if (argc < 4) { fprintf(stderr, "usage: %s N seed out [threads]\n", argv[0]); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: %s N seed out [threads] [0x]\n", argv[0]); return 2; }
   const uint64_t n = strtoull(argv[1], NULL, 0), seed = strtoull(argv[2], NULL, 0);
   int t = argc > 4 ? atoi(argv[4]) : 16;
   if (t < 1) t = 1;
   if (t > 256) t = 256;
+  const int lead = argc > 5 && argv[5][0] == '0' ? 2 : 0;
   const int fd = open(argv[3], O_CREAT | O_TRUNC | O_WRONLY, 0644);
-  if (fd < 0 || ftruncate(fd, (off_t)(n * 65)) != 0) { perror(argv[3]); return 1; }
+  if (fd < 0 || ftruncate(fd, (off_t)(n * (uint64_t)(65 + lead))) != 0) { perror(argv[3]); return 1; }
   pthread_t th[256];
   job_t job[256];
   for (int i = 0; i < t; ++i) {
-    job[i] = (job_t){fd, seed, n * (uint64_t)i / (uint64_t)t, n * (uint64_t)(i + 1) / (uint64_t)t};
+    job[i] = (job_t){fd, seed, n * (uint64_t)i / (uint64_t)t, n * (uint64_t)(i + 1) / (uint64_t)t, lead};
     pthread_create(&th[i], NULL, work, &job[i]);
   }
   for (int i = 0; i < t; ++i) pthread_join(th[i], NULL);
