@@ -450,6 +450,9 @@ static void *mul_reader(void *arg) {
     if (map != MAP_FAILED) {
       madvise(map, size, MADV_SEQUENTIAL);
       q->map = map, q->map_size = size;
+      /* (populating each chunk's pages from this thread ahead of the parse threads - madvise MADV_POPULATE_READ - was measured in round 6 and
+         is slower: 2^30 hex lines through this reader 565-595 against 657-671 M lines/s, -raw 974-989 against 1137-1142: the call holds the
+         address-space lock the device threads' launches and copies need, like the munmap that cmd_mul now puts off) */
       size_t stop = size; /* where this stretch ends: the first line end at or after pos + limit (records of -bin: a multiple of 32) */
       if (q->limit && (size_t)pos + q->limit < size) {
         stop = (size_t)pos + q->limit;
